@@ -1,0 +1,38 @@
+/*
+ * rt_host.h — C entry points of the host-side library (librt_host.so): the scene
+ * loader and frame renderer that sit above the tracer's C-ABI (rt_amd.h).
+ *
+ * These wrap the C++ interfaces that mirror the reference's
+ * SceneLoader::loadFromFile (reference include/SceneLoader.h:60) and
+ * Renderer::renderFrame (reference include/Renderer.h:143-144) so that a non-C++
+ * host (the Python tests and bench.py) can drive them.  Every function returns 0
+ * on success and a non-zero code on failure; rth_last_error() gives the text of
+ * the exception the C++ layer threw.  No exception crosses this boundary.
+ */
+#ifndef RT_HOST_H
+#define RT_HOST_H
+
+#include "rt_scene.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rth_scene rth_scene;
+
+const char* rth_last_error(void);
+
+/* Load a scene JSON (reference key set) and flatten it. */
+int rth_scene_load(const char* json_path, rth_scene** out);
+/* The flattened description; valid until rth_scene_free. */
+const rt_scene* rth_scene_get(const rth_scene* scene);
+/* Mutable access to the settings block (tests shrink photon counts etc.). */
+rt_settings* rth_scene_settings(rth_scene* scene);
+int rth_scene_write(const rth_scene* scene, const char* path);
+void rth_scene_free(rth_scene* scene);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* RT_HOST_H */

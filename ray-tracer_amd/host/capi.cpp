@@ -1,0 +1,60 @@
+// C entry points over the C++ host layer (include/rt_host.h).
+
+#include "rt_host.h"
+
+#include "Flatten.h"
+#include "SceneLoader.h"
+#include "rt_scene_io.h"
+
+#include <string>
+
+struct rth_scene
+{
+    LoadedScene loaded;
+    FlatScene flat;
+};
+
+namespace
+{
+thread_local std::string g_error;
+}
+
+extern "C" {
+
+const char* rth_last_error(void) { return g_error.c_str(); }
+
+int rth_scene_load(const char* json_path, rth_scene** out)
+{
+    *out = nullptr;
+    try
+    {
+        auto scene = std::make_unique<rth_scene>();
+        scene->loaded = SceneLoader::loadFromFile(json_path);
+        flattenScene(scene->loaded, scene->flat);
+        *out = scene.release();
+        return 0;
+    }
+    catch (const std::exception& e)
+    {
+        g_error = e.what();
+        return 1;
+    }
+}
+
+const rt_scene* rth_scene_get(const rth_scene* scene) { return &scene->flat.scene; }
+
+rt_settings* rth_scene_settings(rth_scene* scene) { return &scene->flat.scene.settings; }
+
+int rth_scene_write(const rth_scene* scene, const char* path)
+{
+    const int rc = rt_scene_write(&scene->flat.scene, path);
+    if (rc != 0)
+    {
+        g_error = std::string("cannot write ") + path;
+    }
+    return rc;
+}
+
+void rth_scene_free(rth_scene* scene) { delete scene; }
+
+}  // extern "C"
