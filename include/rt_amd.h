@@ -1,0 +1,172 @@
+/*
+ * rt_amd.h — C-ABI of the MI355X photon tracer (librt_amd.so).
+ *
+ * The reference has no FFI layer: its photon pass is the C++ `Worker` thread loop
+ * wired up by `Renderer::renderFrame` (reference src/Renderer.cpp:421-464) and read
+ * back through `WorkerDebug::*` counters, `Buffer` and `BounceStore`.  This header is
+ * the boundary a replacement for that loop exposes: plain pointers and sizes, integer
+ * status codes, no exceptions and no C++/torch types.  Each entry point names the
+ * reference interface it stands in for.
+ *
+ * Conventions
+ *   - every function returns RT_OK (0) or an RT_ERR_* code; rt_last_error() returns
+ *     the message of the calling thread's last failure.
+ *   - the caller owns every host pointer it passes; a handle owns its device memory
+ *     unless a buffer was bound with rt_bind_*.
+ *   - a handle is bound to one GPU and is not thread-safe; use one host thread (or
+ *     one process) per GPU.
+ *   - all kernels are launched on the handle's stream (rt_set_stream; default: the
+ *     null stream); rt_trace is asynchronous, every rt_read_* synchronises first.
+ *   - there is NO CPU fallback: without a usable GPU every call that computes fails
+ *     with RT_ERR_DEVICE.
+ */
+#ifndef RT_AMD_H
+#define RT_AMD_H
+
+#include "rt_scene.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum
+{
+    RT_OK = 0,
+    RT_ERR_ARGUMENT = 1, /* bad pointer / size / index / unsupported scene feature */
+    RT_ERR_DEVICE = 2,   /* HIP runtime failure (message carries hipGetErrorString) */
+    RT_ERR_STATE = 3     /* call made in the wrong order (e.g. trace before sink set-up) */
+};
+
+enum rt_sink_mode
+{
+    RT_SINK_NONE = 0,  /* transport only (counters + records) */
+    RT_SINK_PROBE = 1, /* default mode: probe keep-test + raw bounce store
+                          (reference src/Worker.cpp:578-607) */
+    RT_SINK_SPLAT = 2  /* legacy mode: density grid + direct camera splat
+                          (reference src/Worker.cpp:608-625) */
+};
+
+typedef struct rt_tracer rt_tracer;
+
+/* Counters of one trace, the WorkerDebug::* set (reference include/Worker.h:220-246)
+ * plus the transport totals the benchmark metric is made of. */
+typedef struct rt_counters
+{
+    uint64_t photons;                 /* photons emitted and traced */
+    uint64_t casts;                   /* scene casts, including the one that escapes */
+    uint64_t bounces;                 /* casts that produced a valid hit (> 1e-4)     */
+    uint64_t deposits;                /* non-delta bounces                            */
+    uint64_t kept;                    /* WorkerDebug::bounceKept()                    */
+    uint64_t culled;                  /* WorkerDebug::bounceCulled()                  */
+    uint64_t store_attempted;         /* BounceStore::attemptedCount()                */
+    uint64_t store_size;              /* BounceStore::size()                          */
+    uint64_t store_dropped;           /* BounceStore::droppedCount()                  */
+    uint64_t splat_total;             /* WorkerDebug::splatTotal()                    */
+    uint64_t splat_radius_clamped;    /* WorkerDebug::splatRadiusClamped()            */
+    uint64_t splat_luminance_clamped; /* WorkerDebug::splatLuminanceClamped()         */
+    uint64_t density_cells;           /* DensityGrid::cellCount()                     */
+    uint64_t density_deposits;        /* DensityGrid::depositCount()                  */
+    double deposited_power[3];        /* sum of photon power over all non-delta bounces */
+} rt_counters;
+
+typedef struct rt_trace_params
+{
+    int32_t sink_mode;       /* rt_sink_mode */
+    int32_t reserved;
+    uint64_t first_photon;   /* per light: trace photon indices [first, first+count)   */
+    uint64_t photon_count;   /* 0 = settings.photons_per_light - first_photon           */
+    uint64_t record_photons; /* keep per-bounce records of the first M photons traced   */
+} rt_trace_params;
+
+const char* rt_last_error(void);
+
+/* sizeof() of the ABI structs as this library was compiled, for binding checks:
+ * which = 0 rt_scene, 1 rt_volume, 2 rt_mesh, 3 rt_material, 4 rt_light, 5 rt_camera,
+ * 6 rt_settings, 7 rt_counters, 8 rt_trace_params. */
+uint64_t rt_abi_struct_size(int32_t which);
+
+/* Number of usable GPUs (0 when there is none). */
+int32_t rt_device_count(void);
+
+/* Build a tracer for `scene` on GPU `device`: builds each mesh's tree with the
+ * reference's median-split algorithm (reference src/Tree.cpp:289-362), flattens it,
+ * and uploads volumes, materials, lights and cameras.  Stands in for the Worker
+ * wiring block of Renderer::renderFrame (reference src/Renderer.cpp:421-459). */
+int32_t rt_create(const rt_scene* scene, int32_t device, rt_tracer** out);
+void rt_destroy(rt_tracer* tracer);
+
+/* Launch on this HIP stream (a hipStream_t passed as void*; NULL = null stream). */
+int32_t rt_set_stream(rt_tracer* tracer, void* hip_stream);
+
+/* Sink A set-up: the ProbeIndex (reference src/ProbeIndex.cpp:5-25) over `probes`
+ * [n][3] with cubic cells of `cell_size`, the keep radius, and a BounceStore of
+ * `store_capacity` records (reference src/BounceStore.cpp:5-9). */
+int32_t rt_set_probes(rt_tracer* tracer, const double* probes, uint64_t n, double cell_size,
+                      double keep_radius, uint64_t store_capacity);
+
+/* Sink B set-up: Worker::setMinSplatRadius / setSplatTargets / the DensityGrid
+ * (reference src/Renderer.cpp:196-274,445-457).  density_cell_size <= 0 disables the
+ * grid; density_capacity is the number of hash slots reserved for occupied cells. */
+int32_t rt_set_splat(rt_tracer* tracer, double min_splat_radius, double density_cell_size,
+                     uint64_t density_capacity);
+
+/* Use caller-owned DEVICE memory for camera `camera`'s splat buffer ([h][w][3]
+ * floats) so that a framework can all-reduce it in place.  NULL returns to the
+ * internal buffer. */
+int32_t rt_bind_camera_buffer(rt_tracer* tracer, int32_t camera, float* device_rgb);
+
+/* Zero the camera buffers, the bounce store cursor, the density grid, the counters
+ * (Buffer::clear, reference src/Buffer.cpp:14-20; WorkerDebug::reset*Counters). */
+int32_t rt_reset(rt_tracer* tracer);
+
+/* The photon pass: emit and trace the photon range of every light (reference
+ * Worker::exec / processLights / processPhotons, src/Worker.cpp:116-174,429-680).
+ * Asynchronous on the handle's stream; accumulates into sinks and counters until
+ * rt_reset. */
+int32_t rt_trace(rt_tracer* tracer, const rt_trace_params* params);
+int32_t rt_synchronize(rt_tracer* tracer);
+
+int32_t rt_read_counters(rt_tracer* tracer, rt_counters* out);
+/* Buffer::fetchColor over the whole image: rgb [h][w][3] (reference src/Buffer.cpp:39-53). */
+int32_t rt_read_camera_buffer(rt_tracer* tracer, int32_t camera, float* rgb);
+/* BounceStore records, 13 floats each (reference include/BounceStore.h:55-113):
+ * px py pz ix iy iz nx ny nz time power_r power_g power_b. */
+int32_t rt_read_store(rt_tracer* tracer, float* records, uint64_t max_records, uint64_t* count);
+/* DensityGrid cells: keys [n][3] int64, power [n][3] float, counts [n] uint64. */
+int32_t rt_read_density(rt_tracer* tracer, int64_t* keys, float* power, uint64_t* counts,
+                        uint64_t max_cells, uint64_t* count);
+/* Per-bounce records of the last trace (layout: oracle.h / DESIGN.md "records"):
+ * emitted [M][6], casts_valid [M][2], f64 [M][B][10], i32 [M][B][8], power [M][B][3]
+ * with B = bounce_threshold + 1.  Any pointer may be NULL. */
+int32_t rt_read_records(rt_tracer* tracer, uint64_t* recorded, double* emitted, int32_t* casts_valid,
+                        double* bounce_f64, int32_t* bounce_i32, float* bounce_power);
+
+/* ---- function-level entry points (device-executed; host pointers in and out) ----
+ * Same row layouts as the reference-generated vectors under tests/golden/. */
+
+/* Closest valid hit of world rays against the whole scene (reference
+ * src/Worker.cpp:538-573): rays [n][6] -> f64 [n][7] position normal distance,
+ * i32 [n][4] hit volume triangle material. */
+int32_t rt_cast_rays(rt_tracer* tracer, int64_t n, const double* rays, double self_hit,
+                     double* out_f64, int32_t* out_i32);
+/* Light::emit from explicit draws, 5 per photon (reference src/OmniLight.cpp:23-44,
+ * src/SpotLight.cpp:50-70, src/ParallelLight.cpp:26-47, src/AreaLight.cpp:106-155). */
+int32_t rt_emit(rt_tracer* tracer, int32_t light, int64_t n, const double* draws5,
+                uint64_t total_photons, double* rays, float* colors);
+/* rayIntersectsTriangle / Bounds / Sphere / Quad / Plane (reference src/Ray.cpp:16-375). */
+int32_t rt_intersect_triangles(int32_t device, int64_t n, const double* in24, double* out8);
+int32_t rt_intersect_bounds(int32_t device, int64_t n, const double* in12, int32_t* out);
+int32_t rt_intersect_spheres(int32_t device, int64_t n, const double* in10, double* out8);
+int32_t rt_intersect_quads(int32_t device, int64_t n, const double* in15, double* out20);
+int32_t rt_intersect_planes(int32_t device, int64_t n, const double* in10, double* out8);
+/* Material::sample with explicit draws / Material::evaluate + pdf (reference
+ * src/LambertianMaterial.cpp, MirrorMaterial.cpp, DielectricMaterial.cpp,
+ * MicrofacetMaterial.cpp): in [n][14] -> out [n][10] / [n][4]. */
+int32_t rt_bsdf_sample(int32_t device, int64_t n, const double* in14, double* out10);
+int32_t rt_bsdf_evaluate(int32_t device, int64_t n, const double* in14, double* out4);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* RT_AMD_H */

@@ -1,0 +1,956 @@
+// rt_api.hip — the C-ABI of include/rt_amd.h: scene flattening and upload, sink
+// set-up, launches and read-back.  Host code only; every kernel lives in
+// rt_kernels.hip.
+
+#include "rt_amd.h"
+
+#include "rt_bvh.h"
+#include "rt_kernels.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <tuple>
+#include <vector>
+
+namespace
+{
+
+thread_local std::string g_error;
+
+struct ApiError : std::runtime_error
+{
+    int code;
+    ApiError(int c, const std::string& what) : std::runtime_error(what), code(c) {}
+};
+
+void check(hipError_t e, const char* what)
+{
+    if (e != hipSuccess)
+    {
+        throw ApiError(RT_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
+    }
+}
+
+void require(bool ok, const char* what)
+{
+    if (!ok)
+    {
+        throw ApiError(RT_ERR_ARGUMENT, what);
+    }
+}
+
+template <typename T>
+struct DeviceArray
+{
+    T* ptr = nullptr;
+    size_t count = 0;
+    DeviceArray() = default;
+    DeviceArray(const DeviceArray&) = delete;
+    DeviceArray& operator=(const DeviceArray&) = delete;
+    ~DeviceArray() { release(); }
+    void release()
+    {
+        if (ptr)
+        {
+            (void)hipFree(ptr);
+            ptr = nullptr;
+            count = 0;
+        }
+    }
+    void allocate(size_t n)
+    {
+        release();
+        if (n > 0)
+        {
+            check(hipMalloc(reinterpret_cast<void**>(&ptr), n * sizeof(T)), "hipMalloc");
+            count = n;
+        }
+    }
+    void upload(const std::vector<T>& host)
+    {
+        allocate(host.size());
+        if (!host.empty())
+        {
+            check(hipMemcpy(ptr, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice), "hipMemcpy H2D");
+        }
+    }
+    void zero(hipStream_t stream)
+    {
+        if (ptr)
+        {
+            check(hipMemsetAsync(ptr, 0, count * sizeof(T), stream), "hipMemsetAsync");
+        }
+    }
+};
+
+rtd::Quat quatInverse(const rtd::Quat& q)  // reference src/Quaternion.cpp:39-52
+{
+    const double m = q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w;
+    const double s = 1.0 / m;
+    return rtd::Quat{-q.x * s, -q.y * s, -q.z * s, q.w * s};
+}
+
+// Host copy of the device quaternion product (reference src/Quaternion.cpp:88-109);
+// used once per light / camera to resolve forward / right / up.
+void hostRotate(const double* q, const double* v, double* out)
+{
+    const double px = v[0], py = v[1], pz = v[2], pw = 0.0;
+    const double qx = q[0], qy = q[1], qz = q[2], qw = q[3];
+    const double ax = qw * px + qx * pw + qy * pz - qz * py;
+    const double ay = qw * py + qy * pw + qz * px - qx * pz;
+    const double az = qw * pz + qz * pw + qx * py - qy * px;
+    const double aw = qw * pw - qx * px - qy * py - qz * pz;
+    const double cx = -qx, cy = -qy, cz = -qz, cw = qw;
+    out[0] = aw * cx + ax * cw + ay * cz - az * cy;
+    out[1] = aw * cy + ay * cw + az * cx - ax * cz;
+    out[2] = aw * cz + az * cw + ax * cy - ay * cx;
+}
+
+double radians(double degrees) { return M_PI * (degrees / 180.0); }  // reference src/Utility.cpp:35-38
+
+}  // namespace
+
+struct rt_tracer
+{
+    int device = 0;
+    hipStream_t stream = nullptr;
+    rt_settings settings{};
+    std::vector<rt_camera> cameraDesc;
+    int64_t lightCount = 0;
+
+    DeviceArray<rtd::Volume> volumes;
+    DeviceArray<rtd::Node> nodes;
+    DeviceArray<double> triPos, triNrm;
+    DeviceArray<int32_t> triId;
+    DeviceArray<rtd::Material> materials;
+    DeviceArray<rtd::Light> lights;
+    DeviceArray<rtd::Camera> cameras;
+    std::vector<rtd::Camera> cameraHost;
+    std::vector<std::unique_ptr<DeviceArray<float>>> cameraBuffers;
+    std::vector<float*> boundBuffers;
+
+    // sink A
+    bool probesSet = false;
+    DeviceArray<int64_t> slotKey;
+    DeviceArray<uint32_t> slotStart, slotCount;
+    DeviceArray<double> probePoints;
+    rtd::ProbeView probeView{};
+    DeviceArray<float> storeRecords;
+    uint64_t storeCapacity = 0;
+
+    // sink B
+    bool splatSet = false;
+    double minSplatRadius = 0.0;
+    DeviceArray<unsigned long long> densityKeys, densityCount;
+    DeviceArray<float> densityPower;
+    rtd::DensityView densityView{};
+
+    // shared device scalars: [0] work counter, [1] store cursor
+    DeviceArray<unsigned long long> scalars;
+    DeviceArray<rtd::DeviceCounters> counters;
+
+    // records of the last trace
+    uint64_t recordPhotons = 0;
+    DeviceArray<double> recEmitted, recF64;
+    DeviceArray<int32_t> recCasts, recI32;
+    DeviceArray<float> recPower;
+
+    rtd::SceneView view{};
+    int blocks = 0;
+};
+
+namespace
+{
+
+void activate(const rt_tracer* t) { check(hipSetDevice(t->device), "hipSetDevice"); }
+
+void buildScene(rt_tracer* t, const rt_scene* scene)
+{
+    require(scene != nullptr, "scene is null");
+    require(scene->volume_count >= 0 && scene->mesh_count >= 0 && scene->material_count > 0, "bad scene counts");
+    t->settings = scene->settings;
+    t->lightCount = scene->light_count;
+
+    // ---- meshes: reference tree, flattened; triangles re-ordered by page ----
+    std::vector<rtd::Node> nodes;
+    std::vector<double> triPos, triNrm;
+    std::vector<int32_t> triId;
+    struct MeshSpan
+    {
+        int32_t nodeBase, nodeCount;
+        int64_t triBase;
+    };
+    std::vector<MeshSpan> spans;
+    for (int64_t m = 0; m < scene->mesh_count; ++m)
+    {
+        const rt_mesh& mesh = scene->meshes[m];
+        require(mesh.first_triangle >= 0 && mesh.triangle_count >= 0 &&
+                    mesh.first_triangle + mesh.triangle_count <= scene->triangle_count,
+                "mesh triangle range out of bounds");
+        require(mesh.triangle_count < (1ll << 30), "mesh too large");
+        const double* pos = scene->tri_pos + 9 * mesh.first_triangle;
+        const double* nrm = scene->tri_nrm + 9 * mesh.first_triangle;
+        rtbvh::FlatMesh flat = rtbvh::build(pos, mesh.triangle_count);
+        MeshSpan span;
+        span.nodeBase = static_cast<int32_t>(nodes.size());
+        span.nodeCount = static_cast<int32_t>(flat.nodes.size());
+        span.triBase = static_cast<int64_t>(triId.size());
+        for (const rtbvh::FlatNode& fn : flat.nodes)
+        {
+            rtd::Node n;
+            std::memcpy(n.bmin, fn.bmin, sizeof(n.bmin));
+            std::memcpy(n.bmax, fn.bmax, sizeof(n.bmax));
+            n.skip = fn.skip;
+            n.triStart = fn.triStart;
+            n.triCount = fn.triCount;
+            n.pad = 0;
+            nodes.push_back(n);
+        }
+        for (int32_t original : flat.order)
+        {
+            triPos.insert(triPos.end(), pos + 9 * original, pos + 9 * original + 9);
+            triNrm.insert(triNrm.end(), nrm + 9 * original, nrm + 9 * original + 9);
+            triId.push_back(original);
+        }
+        spans.push_back(span);
+    }
+
+    // ---- volumes ----
+    std::vector<rtd::Volume> volumes;
+    for (int64_t i = 0; i < scene->volume_count; ++i)
+    {
+        const rt_volume& rv = scene->volumes[i];
+        require(rv.material >= 0 && rv.material < scene->material_count, "volume material index out of range");
+        rtd::Volume v{};
+        v.type = rv.type;
+        v.material = rv.material;
+        std::memcpy(v.pos, rv.position, sizeof(v.pos));
+        v.rot = rtd::Quat{rv.rotation[0], rv.rotation[1], rv.rotation[2], rv.rotation[3]};
+        v.inv = quatInverse(v.rot);
+        std::memcpy(v.param, rv.param, sizeof(v.param));
+        if (rv.type == RT_VOLUME_MESH)
+        {
+            require(rv.mesh >= 0 && rv.mesh < scene->mesh_count, "volume mesh index out of range");
+            v.nodeBase = spans[rv.mesh].nodeBase;
+            v.nodeCount = spans[rv.mesh].nodeCount;
+            v.triBase = spans[rv.mesh].triBase;
+        }
+        else
+        {
+            require(rv.type == RT_VOLUME_SPHERE || rv.type == RT_VOLUME_QUAD || rv.type == RT_VOLUME_PLANE,
+                    "unknown volume type");
+        }
+        volumes.push_back(v);
+    }
+
+    // ---- materials ----
+    std::vector<rtd::Material> materials;
+    for (int64_t i = 0; i < scene->material_count; ++i)
+    {
+        const rt_material& rm = scene->materials[i];
+        require(rm.type >= RT_MATERIAL_LAMBERTIAN && rm.type <= RT_MATERIAL_MICROFACET, "unknown material type");
+        rtd::Material m{};
+        m.type = rm.type;
+        std::memcpy(m.color, rm.color, sizeof(m.color));
+        m.alpha = rm.alpha;
+        m.ior = rm.ior;
+        materials.push_back(m);
+    }
+
+    // ---- lights ----
+    std::vector<rtd::Light> lights;
+    for (int64_t i = 0; i < scene->light_count; ++i)
+    {
+        const rt_light& rl = scene->lights[i];
+        require(rl.type >= RT_LIGHT_OMNI && rl.type <= RT_LIGHT_AREA, "unknown light type");
+        require(rl.type != RT_LIGHT_SPOT || rl.linearity == 1.0,
+                "spot light linearity other than 1 is not supported on the device");
+        rtd::Light l{};
+        l.type = rl.type;
+        l.shape = rl.shape;
+        std::memcpy(l.pos, rl.position, sizeof(l.pos));
+        l.rot = rtd::Quat{rl.rotation[0], rl.rotation[1], rl.rotation[2], rl.rotation[3]};
+        const double unitZ[3] = {0, 0, 1};
+        hostRotate(rl.rotation, unitZ, l.forward);  // Object::forward, reference src/Object.cpp:45-48
+        std::memcpy(l.color, rl.color, sizeof(l.color));
+        l.flux = rl.luminous_flux;
+        l.innerRadius = rl.inner_radius;
+        l.maxAngle = rl.max_angle;
+        l.radius = rl.radius;
+        l.width = rl.width;
+        l.height = rl.height;
+        lights.push_back(l);
+    }
+
+    // ---- cameras (projection constants of reference src/Camera.cpp:239-275 and the
+    //      pixel half angle of src/Worker.cpp:344-363, resolved once on the host) ----
+    t->cameraDesc.assign(scene->cameras, scene->cameras + scene->camera_count);
+    t->cameraHost.clear();
+    t->cameraBuffers.clear();
+    for (int64_t i = 0; i < scene->camera_count; ++i)
+    {
+        t->cameraBuffers.emplace_back(new DeviceArray<float>());
+    }
+    t->boundBuffers.assign(static_cast<size_t>(scene->camera_count), nullptr);
+    const float start = static_cast<float>(scene->settings.frame_time);
+    const float shutter = static_cast<float>(scene->settings.shutter_time);
+    const float windowStart = start;  // reference src/Renderer.cpp:145-179
+    const float windowEnd = shutter > 0.0f ? start + shutter : std::numeric_limits<float>::infinity();
+    for (int64_t i = 0; i < scene->camera_count; ++i)
+    {
+        const rt_camera& rc = scene->cameras[i];
+        require(rc.width > 0 && rc.height > 0, "camera resolution must be positive");
+        rtd::Camera c{};
+        std::memcpy(c.pos, rc.position, sizeof(c.pos));
+        const double ux[3] = {1, 0, 0}, uy[3] = {0, 1, 0}, uz[3] = {0, 0, 1};
+        hostRotate(rc.rotation, ux, c.right);
+        hostRotate(rc.rotation, uy, c.up);
+        hostRotate(rc.rotation, uz, c.forward);
+        c.aspect = static_cast<double>(rc.width) / static_cast<double>(rc.height);
+        c.halfHeight = std::tan(radians(rc.vertical_fov_degrees) / 2.0);
+        const double pixelHalfAngle = 0.5 * radians(rc.vertical_fov_degrees) / static_cast<double>(rc.height);
+        c.tanPixelHalfAngle = std::tan(pixelHalfAngle);
+        c.width = rc.width;
+        c.height = rc.height;
+        c.bounceFilter = rc.bounce_filter;
+        c.lightFilter = rc.light_filter;
+        c.windowStart = windowStart;
+        c.windowEnd = windowEnd;
+        t->cameraBuffers[i]->allocate(static_cast<size_t>(rc.width) * rc.height * 3);
+        c.buffer = t->cameraBuffers[i]->ptr;
+        t->cameraHost.push_back(c);
+    }
+
+    t->volumes.upload(volumes);
+    t->nodes.upload(nodes);
+    t->triPos.upload(triPos);
+    t->triNrm.upload(triNrm);
+    t->triId.upload(triId);
+    t->materials.upload(materials);
+    t->lights.upload(lights);
+    t->cameras.upload(t->cameraHost);
+    t->scalars.allocate(4);
+    t->counters.allocate(1);
+
+    rtd::SceneView& view = t->view;
+    view.volumes = t->volumes.ptr;
+    view.nodes = t->nodes.ptr;
+    view.triPos = t->triPos.ptr;
+    view.triNrm = t->triNrm.ptr;
+    view.triId = t->triId.ptr;
+    view.materials = t->materials.ptr;
+    view.lights = t->lights.ptr;
+    view.cameras = t->cameras.ptr;
+    view.volumeCount = static_cast<int32_t>(volumes.size());
+    view.lightCount = static_cast<int32_t>(lights.size());
+    view.cameraCount = static_cast<int32_t>(t->cameraHost.size());
+    view.bounceThreshold = scene->settings.bounce_threshold;
+    view.terminationThreshold = std::max(0.0, scene->settings.termination_threshold);  // reference src/Worker.cpp:194-199
+    view.splatLuminanceClamp = std::max(0.0, scene->settings.splat_luminance_clamp);
+    view.photonsPerLight = scene->settings.photons_per_light;
+    view.seed = scene->settings.seeded ? scene->settings.seed : 0u;
+    view.windowStart = windowStart;
+    view.windowEnd = windowEnd;
+    view.hasCamera = scene->camera_count > 0 ? 1 : 0;
+}
+
+void resetState(rt_tracer* t)
+{
+    t->scalars.zero(t->stream);
+    t->counters.zero(t->stream);
+    for (size_t c = 0; c < t->cameraHost.size(); ++c)
+    {
+        const size_t bytes = static_cast<size_t>(t->cameraHost[c].width) * t->cameraHost[c].height * 3 * sizeof(float);
+        check(hipMemsetAsync(t->cameraHost[c].buffer, 0, bytes, t->stream), "hipMemsetAsync camera buffer");
+    }
+    if (t->densityKeys.ptr)
+    {
+        check(hipMemsetAsync(t->densityKeys.ptr, 0xFF, t->densityKeys.count * sizeof(unsigned long long), t->stream),
+              "hipMemsetAsync density keys");
+        t->densityPower.zero(t->stream);
+        t->densityCount.zero(t->stream);
+    }
+}
+
+struct CellKey
+{
+    int64_t x, y, z;
+    bool operator<(const CellKey& o) const { return std::tie(x, y, z) < std::tie(o.x, o.y, o.z); }
+};
+
+uint64_t cellSlot(const CellKey& k, uint64_t mask)
+{
+    uint64_t h = static_cast<uint64_t>(k.x) * 73856093ull;  // reference include/ProbeIndex.h:71-80
+    h ^= static_cast<uint64_t>(k.y) * 19349663ull;
+    h ^= static_cast<uint64_t>(k.z) * 83492791ull;
+    return ((h * 0x9E3779B97F4A7C15ull) >> 20) & mask;
+}
+
+template <typename F>
+int32_t guarded(F&& body)
+{
+    try
+    {
+        body();
+        return RT_OK;
+    }
+    catch (const ApiError& e)
+    {
+        g_error = e.what();
+        return e.code;
+    }
+    catch (const std::exception& e)
+    {
+        g_error = e.what();
+        return RT_ERR_ARGUMENT;
+    }
+}
+
+// Run a function-level kernel over host rows: copy in, launch, copy out.
+template <typename Launch>
+void runRows(int32_t device, int64_t n, const void* in, size_t inBytes, void* out, size_t outBytes, Launch&& launch)
+{
+    require(n >= 0, "negative row count");
+    if (n == 0)
+    {
+        return;
+    }
+    require(in != nullptr && out != nullptr, "null buffer");
+    check(hipSetDevice(device), "hipSetDevice");
+    DeviceArray<unsigned char> dIn, dOut;
+    dIn.allocate(inBytes);
+    dOut.allocate(outBytes);
+    check(hipMemcpy(dIn.ptr, in, inBytes, hipMemcpyHostToDevice), "hipMemcpy H2D");
+    launch(dIn.ptr, dOut.ptr);
+    check(hipGetLastError(), "kernel launch");
+    check(hipDeviceSynchronize(), "hipDeviceSynchronize");
+    check(hipMemcpy(out, dOut.ptr, outBytes, hipMemcpyDeviceToHost), "hipMemcpy D2H");
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* rt_last_error(void) { return g_error.c_str(); }
+
+uint64_t rt_abi_struct_size(int32_t which)
+{
+    switch (which)
+    {
+        case 0: return sizeof(rt_scene);
+        case 1: return sizeof(rt_volume);
+        case 2: return sizeof(rt_mesh);
+        case 3: return sizeof(rt_material);
+        case 4: return sizeof(rt_light);
+        case 5: return sizeof(rt_camera);
+        case 6: return sizeof(rt_settings);
+        case 7: return sizeof(rt_counters);
+        case 8: return sizeof(rt_trace_params);
+        default: return 0;
+    }
+}
+
+int32_t rt_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess)
+    {
+        return 0;
+    }
+    return n;
+}
+
+int32_t rt_create(const rt_scene* scene, int32_t device, rt_tracer** out)
+{
+    if (out == nullptr)
+    {
+        g_error = "out is null";
+        return RT_ERR_ARGUMENT;
+    }
+    *out = nullptr;
+    return guarded([&]() {
+        int n = 0;
+        check(hipGetDeviceCount(&n), "hipGetDeviceCount");
+        if (device < 0 || device >= n)
+        {
+            throw ApiError(RT_ERR_DEVICE, "no such GPU (device " + std::to_string(device) + " of " + std::to_string(n) + ")");
+        }
+        check(hipSetDevice(device), "hipSetDevice");
+        std::unique_ptr<rt_tracer> t(new rt_tracer());
+        t->device = device;
+        buildScene(t.get(), scene);
+        hipDeviceProp_t prop{};
+        check(hipGetDeviceProperties(&prop, device), "hipGetDeviceProperties");
+        t->blocks = prop.multiProcessorCount * rtd::traceBlocksPerCu();
+        resetState(t.get());
+        check(hipStreamSynchronize(t->stream), "hipStreamSynchronize");
+        *out = t.release();
+    });
+}
+
+void rt_destroy(rt_tracer* tracer)
+{
+    if (tracer)
+    {
+        (void)hipSetDevice(tracer->device);
+        (void)hipDeviceSynchronize();
+        delete tracer;
+    }
+}
+
+int32_t rt_set_stream(rt_tracer* tracer, void* hip_stream)
+{
+    return guarded([&]() {
+        require(tracer != nullptr, "tracer is null");
+        tracer->stream = static_cast<hipStream_t>(hip_stream);
+    });
+}
+
+int32_t rt_set_probes(rt_tracer* tracer, const double* probes, uint64_t n, double cell_size, double keep_radius,
+                      uint64_t store_capacity)
+{
+    return guarded([&]() {
+        require(tracer != nullptr, "tracer is null");
+        require(n == 0 || probes != nullptr, "probes is null");
+        require(n < (1ull << 32), "too many probes");
+        activate(tracer);
+        // ProbeIndex constructor, reference src/ProbeIndex.cpp:5-16
+        const double cellSize = cell_size > 0.0 ? cell_size : 1.0;
+        const double invCellSize = 1.0 / cellSize;
+        const double keepRadius = keep_radius > 0.0 ? keep_radius : 0.0;
+        std::map<CellKey, std::vector<uint32_t>> cells;
+        for (uint64_t i = 0; i < n; ++i)
+        {
+            const CellKey key{static_cast<int64_t>(std::floor(probes[3 * i] * invCellSize)),
+                              static_cast<int64_t>(std::floor(probes[3 * i + 1] * invCellSize)),
+                              static_cast<int64_t>(std::floor(probes[3 * i + 2] * invCellSize))};
+            cells[key].push_back(static_cast<uint32_t>(i));
+        }
+        uint64_t slots = 16;
+        while (slots < 2 * cells.size() + 1)
+        {
+            slots <<= 1;
+        }
+        std::vector<int64_t> slotKey(3 * slots, 0);
+        std::vector<uint32_t> slotStart(slots, 0), slotCount(slots, 0);
+        std::vector<double> points;
+        points.reserve(3 * n);
+        for (const auto& cell : cells)
+        {
+            uint64_t slot = cellSlot(cell.first, slots - 1);
+            while (slotCount[slot] != 0)
+            {
+                slot = (slot + 1) & (slots - 1);
+            }
+            slotKey[3 * slot + 0] = cell.first.x;
+            slotKey[3 * slot + 1] = cell.first.y;
+            slotKey[3 * slot + 2] = cell.first.z;
+            slotStart[slot] = static_cast<uint32_t>(points.size() / 3);
+            slotCount[slot] = static_cast<uint32_t>(cell.second.size());
+            for (uint32_t index : cell.second)
+            {
+                points.insert(points.end(), probes + 3 * index, probes + 3 * index + 3);
+            }
+        }
+        tracer->slotKey.upload(slotKey);
+        tracer->slotStart.upload(slotStart);
+        tracer->slotCount.upload(slotCount);
+        tracer->probePoints.upload(points);
+        rtd::ProbeView& pv = tracer->probeView;
+        pv.slotKey = tracer->slotKey.ptr;
+        pv.slotStart = tracer->slotStart.ptr;
+        pv.slotCount = tracer->slotCount.ptr;
+        pv.points = tracer->probePoints.ptr;
+        pv.slotMask = slots - 1;
+        pv.probeCount = n;
+        pv.invCellSize = invCellSize;
+        pv.keepRadius = keepRadius;
+        pv.reach = static_cast<int64_t>(std::ceil(keepRadius * invCellSize));
+        require(pv.reach <= 64, "keep radius spans too many probe cells");
+        tracer->storeCapacity = store_capacity;
+        tracer->storeRecords.allocate(static_cast<size_t>(store_capacity) * 13);
+        tracer->probesSet = true;
+    });
+}
+
+int32_t rt_set_splat(rt_tracer* tracer, double min_splat_radius, double density_cell_size, uint64_t density_capacity)
+{
+    return guarded([&]() {
+        require(tracer != nullptr, "tracer is null");
+        activate(tracer);
+        tracer->minSplatRadius = std::max(0.0, min_splat_radius);  // reference src/Worker.cpp:211-214
+        rtd::DensityView& dv = tracer->densityView;
+        dv = rtd::DensityView{};
+        tracer->densityKeys.release();
+        tracer->densityPower.release();
+        tracer->densityCount.release();
+        if (density_cell_size > 0.0)
+        {
+            uint64_t slots = 1024;
+            while (slots < 2 * density_capacity)
+            {
+                slots <<= 1;
+            }
+            tracer->densityKeys.allocate(slots);
+            tracer->densityPower.allocate(3 * slots);
+            tracer->densityCount.allocate(slots);
+            dv.keys = tracer->densityKeys.ptr;
+            dv.power = tracer->densityPower.ptr;
+            dv.count = tracer->densityCount.ptr;
+            dv.slotMask = slots - 1;
+            dv.invCellSize = 1.0 / density_cell_size;  // reference src/DensityGrid.cpp:5-9
+            dv.enabled = 1;
+            check(hipMemsetAsync(dv.keys, 0xFF, slots * sizeof(unsigned long long), tracer->stream), "hipMemsetAsync");
+            tracer->densityPower.zero(tracer->stream);
+            tracer->densityCount.zero(tracer->stream);
+        }
+        tracer->splatSet = true;
+    });
+}
+
+int32_t rt_bind_camera_buffer(rt_tracer* tracer, int32_t camera, float* device_rgb)
+{
+    return guarded([&]() {
+        require(tracer != nullptr, "tracer is null");
+        require(camera >= 0 && static_cast<size_t>(camera) < tracer->cameraHost.size(), "camera index out of range");
+        activate(tracer);
+        tracer->boundBuffers[camera] = device_rgb;
+        tracer->cameraHost[camera].buffer = device_rgb ? device_rgb : tracer->cameraBuffers[camera]->ptr;
+        check(hipMemcpyAsync(tracer->cameras.ptr + camera, &tracer->cameraHost[camera], sizeof(rtd::Camera),
+                             hipMemcpyHostToDevice, tracer->stream),
+              "hipMemcpyAsync camera");
+        check(hipStreamSynchronize(tracer->stream), "hipStreamSynchronize");
+    });
+}
+
+int32_t rt_reset(rt_tracer* tracer)
+{
+    return guarded([&]() {
+        require(tracer != nullptr, "tracer is null");
+        activate(tracer);
+        resetState(tracer);
+    });
+}
+
+int32_t rt_trace(rt_tracer* tracer, const rt_trace_params* params)
+{
+    return guarded([&]() {
+        require(tracer != nullptr && params != nullptr, "null argument");
+        activate(tracer);
+        const uint64_t total = tracer->settings.photons_per_light;
+        uint64_t first = std::min<uint64_t>(params->first_photon, total);
+        uint64_t count = params->photon_count;
+        if (count == 0 || first + count > total)
+        {
+            count = total - first;
+        }
+        if (params->sink_mode == RT_SINK_PROBE && !tracer->probesSet)
+        {
+            throw ApiError(RT_ERR_STATE, "rt_set_probes must be called before tracing with RT_SINK_PROBE");
+        }
+        if (params->sink_mode == RT_SINK_SPLAT && !tracer->splatSet)
+        {
+            throw ApiError(RT_ERR_STATE, "rt_set_splat must be called before tracing with RT_SINK_SPLAT");
+        }
+        require(params->sink_mode >= RT_SINK_NONE && params->sink_mode <= RT_SINK_SPLAT, "unknown sink mode");
+
+        rtd::TraceArgs args{};
+        args.scene = tracer->view;
+        args.probes = tracer->probeView;
+        args.store.records = tracer->storeRecords.ptr;
+        args.store.cursor = tracer->scalars.ptr + 1;
+        args.store.capacity = tracer->storeCapacity;
+        args.density = tracer->densityView;
+        args.counters = tracer->counters.ptr;
+        args.workCounter = tracer->scalars.ptr;
+        args.firstPhoton = first;
+        args.photonCount = count;
+        args.totalWork = count * static_cast<uint64_t>(tracer->lightCount);
+        args.minSplatRadius = tracer->minSplatRadius;
+        args.sinkMode = params->sink_mode;
+
+        const int32_t maxBounces = tracer->settings.bounce_threshold + 1;
+        const uint64_t record = std::min<uint64_t>(params->record_photons, args.totalWork);
+        tracer->recordPhotons = record;
+        tracer->recEmitted.allocate(record * 6);
+        tracer->recCasts.allocate(record * 2);
+        tracer->recF64.allocate(record * maxBounces * 10);
+        tracer->recI32.allocate(record * maxBounces * 8);
+        tracer->recPower.allocate(record * maxBounces * 3);
+        tracer->recEmitted.zero(tracer->stream);
+        tracer->recCasts.zero(tracer->stream);
+        tracer->recF64.zero(tracer->stream);
+        if (tracer->recI32.ptr)
+        {
+            check(hipMemsetAsync(tracer->recI32.ptr, 0xFF, tracer->recI32.count * sizeof(int32_t), tracer->stream),
+                  "hipMemsetAsync records");
+        }
+        tracer->recPower.zero(tracer->stream);
+        args.records.recordPhotons = record;
+        args.records.maxBounces = maxBounces;
+        args.records.emitted = tracer->recEmitted.ptr;
+        args.records.castsValid = tracer->recCasts.ptr;
+        args.records.f64 = tracer->recF64.ptr;
+        args.records.i32 = tracer->recI32.ptr;
+        args.records.power = tracer->recPower.ptr;
+
+        // a fresh range of photon ids for this launch
+        check(hipMemsetAsync(tracer->scalars.ptr, 0, sizeof(unsigned long long), tracer->stream), "hipMemsetAsync");
+        if (args.totalWork == 0)
+        {
+            return;
+        }
+        const uint64_t wavesNeeded = (args.totalWork + 63) / 64;
+        const int blocks = static_cast<int>(std::min<uint64_t>(static_cast<uint64_t>(tracer->blocks), (wavesNeeded + 3) / 4));
+        rtd::launchTrace(args, std::max(1, blocks), 256, tracer->stream);
+        check(hipGetLastError(), "trace launch");
+    });
+}
+
+int32_t rt_synchronize(rt_tracer* tracer)
+{
+    return guarded([&]() {
+        require(tracer != nullptr, "tracer is null");
+        activate(tracer);
+        check(hipStreamSynchronize(tracer->stream), "hipStreamSynchronize");
+    });
+}
+
+int32_t rt_read_counters(rt_tracer* tracer, rt_counters* out)
+{
+    return guarded([&]() {
+        require(tracer != nullptr && out != nullptr, "null argument");
+        activate(tracer);
+        check(hipStreamSynchronize(tracer->stream), "hipStreamSynchronize");
+        rtd::DeviceCounters dc{};
+        unsigned long long scalars[4] = {0, 0, 0, 0};
+        check(hipMemcpy(&dc, tracer->counters.ptr, sizeof(dc), hipMemcpyDeviceToHost), "hipMemcpy counters");
+        check(hipMemcpy(scalars, tracer->scalars.ptr, sizeof(scalars), hipMemcpyDeviceToHost), "hipMemcpy scalars");
+        std::memset(out, 0, sizeof(*out));
+        out->photons = dc.photons;
+        out->casts = dc.casts;
+        out->bounces = dc.bounces;
+        out->deposits = dc.deposits;
+        out->kept = dc.kept;
+        out->culled = dc.culled;
+        out->store_attempted = scalars[1];
+        out->store_size = std::min<uint64_t>(scalars[1], tracer->storeCapacity);
+        out->store_dropped = out->store_attempted - out->store_size;
+        out->splat_total = dc.splatTotal;
+        out->splat_radius_clamped = dc.splatRadiusClamped;
+        out->splat_luminance_clamped = dc.splatLuminanceClamped;
+        out->density_cells = dc.densityCells;
+        out->density_deposits = dc.densityDeposits - dc.densityOverflow;
+        for (int k = 0; k < 3; ++k)
+        {
+            out->deposited_power[k] = dc.power[k];
+        }
+        if (dc.densityOverflow != 0)
+        {
+            throw ApiError(RT_ERR_STATE, "density grid overflow: " + std::to_string(dc.densityOverflow) +
+                                             " deposits lost; raise density_capacity in rt_set_splat");
+        }
+    });
+}
+
+int32_t rt_read_camera_buffer(rt_tracer* tracer, int32_t camera, float* rgb)
+{
+    return guarded([&]() {
+        require(tracer != nullptr && rgb != nullptr, "null argument");
+        require(camera >= 0 && static_cast<size_t>(camera) < tracer->cameraHost.size(), "camera index out of range");
+        activate(tracer);
+        check(hipStreamSynchronize(tracer->stream), "hipStreamSynchronize");
+        const rtd::Camera& c = tracer->cameraHost[camera];
+        check(hipMemcpy(rgb, c.buffer, static_cast<size_t>(c.width) * c.height * 3 * sizeof(float), hipMemcpyDeviceToHost),
+              "hipMemcpy camera buffer");
+    });
+}
+
+int32_t rt_read_store(rt_tracer* tracer, float* records, uint64_t max_records, uint64_t* count)
+{
+    return guarded([&]() {
+        require(tracer != nullptr && count != nullptr, "null argument");
+        activate(tracer);
+        check(hipStreamSynchronize(tracer->stream), "hipStreamSynchronize");
+        unsigned long long cursor = 0;
+        check(hipMemcpy(&cursor, tracer->scalars.ptr + 1, sizeof(cursor), hipMemcpyDeviceToHost), "hipMemcpy cursor");
+        const uint64_t size = std::min<uint64_t>(cursor, tracer->storeCapacity);
+        *count = size;
+        const uint64_t n = std::min(size, max_records);
+        if (n > 0)
+        {
+            require(records != nullptr, "records is null");
+            check(hipMemcpy(records, tracer->storeRecords.ptr, n * 13 * sizeof(float), hipMemcpyDeviceToHost),
+                  "hipMemcpy store");
+        }
+    });
+}
+
+int32_t rt_read_density(rt_tracer* tracer, int64_t* keys, float* power, uint64_t* counts, uint64_t max_cells,
+                        uint64_t* count)
+{
+    return guarded([&]() {
+        require(tracer != nullptr && count != nullptr, "null argument");
+        activate(tracer);
+        check(hipStreamSynchronize(tracer->stream), "hipStreamSynchronize");
+        *count = 0;
+        const size_t slots = tracer->densityKeys.count;
+        if (slots == 0)
+        {
+            return;
+        }
+        std::vector<unsigned long long> hKeys(slots), hCount(slots);
+        std::vector<float> hPower(3 * slots);
+        check(hipMemcpy(hKeys.data(), tracer->densityKeys.ptr, slots * sizeof(unsigned long long), hipMemcpyDeviceToHost),
+              "hipMemcpy density keys");
+        check(hipMemcpy(hCount.data(), tracer->densityCount.ptr, slots * sizeof(unsigned long long), hipMemcpyDeviceToHost),
+              "hipMemcpy density counts");
+        check(hipMemcpy(hPower.data(), tracer->densityPower.ptr, 3 * slots * sizeof(float), hipMemcpyDeviceToHost),
+              "hipMemcpy density power");
+        uint64_t n = 0;
+        const int64_t lim = 1 << 20;
+        for (size_t s = 0; s < slots; ++s)
+        {
+            if (hKeys[s] == rtd::kEmptyKey)
+            {
+                continue;
+            }
+            if (n < max_cells && keys && power && counts)
+            {
+                keys[3 * n + 0] = static_cast<int64_t>((hKeys[s] >> 42) & 0x1FFFFF) - lim;
+                keys[3 * n + 1] = static_cast<int64_t>((hKeys[s] >> 21) & 0x1FFFFF) - lim;
+                keys[3 * n + 2] = static_cast<int64_t>(hKeys[s] & 0x1FFFFF) - lim;
+                power[3 * n + 0] = hPower[3 * s + 0];
+                power[3 * n + 1] = hPower[3 * s + 1];
+                power[3 * n + 2] = hPower[3 * s + 2];
+                counts[n] = hCount[s];
+            }
+            ++n;
+        }
+        *count = n;
+    });
+}
+
+int32_t rt_read_records(rt_tracer* tracer, uint64_t* recorded, double* emitted, int32_t* casts_valid,
+                        double* bounce_f64, int32_t* bounce_i32, float* bounce_power)
+{
+    return guarded([&]() {
+        require(tracer != nullptr, "tracer is null");
+        activate(tracer);
+        check(hipStreamSynchronize(tracer->stream), "hipStreamSynchronize");
+        if (recorded)
+        {
+            *recorded = tracer->recordPhotons;
+        }
+        auto fetch = [&](void* dst, const void* src, size_t bytes) {
+            if (dst && bytes > 0)
+            {
+                check(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost), "hipMemcpy records");
+            }
+        };
+        fetch(emitted, tracer->recEmitted.ptr, tracer->recEmitted.count * sizeof(double));
+        fetch(casts_valid, tracer->recCasts.ptr, tracer->recCasts.count * sizeof(int32_t));
+        fetch(bounce_f64, tracer->recF64.ptr, tracer->recF64.count * sizeof(double));
+        fetch(bounce_i32, tracer->recI32.ptr, tracer->recI32.count * sizeof(int32_t));
+        fetch(bounce_power, tracer->recPower.ptr, tracer->recPower.count * sizeof(float));
+    });
+}
+
+int32_t rt_cast_rays(rt_tracer* tracer, int64_t n, const double* rays, double self_hit, double* out_f64,
+                     int32_t* out_i32)
+{
+    return guarded([&]() {
+        require(tracer != nullptr, "tracer is null");
+        require(n >= 0, "negative ray count");
+        if (n == 0)
+        {
+            return;
+        }
+        require(rays && out_f64 && out_i32, "null buffer");
+        activate(tracer);
+        DeviceArray<double> dRays, dF;
+        DeviceArray<int32_t> dI;
+        dRays.allocate(6 * n);
+        dF.allocate(7 * n);
+        dI.allocate(4 * n);
+        check(hipMemcpy(dRays.ptr, rays, 6 * n * sizeof(double), hipMemcpyHostToDevice), "hipMemcpy rays");
+        rtd::launchCastRays(tracer->view, n, dRays.ptr, self_hit, dF.ptr, dI.ptr, tracer->stream);
+        check(hipGetLastError(), "cast launch");
+        check(hipStreamSynchronize(tracer->stream), "hipStreamSynchronize");
+        check(hipMemcpy(out_f64, dF.ptr, 7 * n * sizeof(double), hipMemcpyDeviceToHost), "hipMemcpy hits");
+        check(hipMemcpy(out_i32, dI.ptr, 4 * n * sizeof(int32_t), hipMemcpyDeviceToHost), "hipMemcpy ids");
+    });
+}
+
+int32_t rt_emit(rt_tracer* tracer, int32_t light, int64_t n, const double* draws5, uint64_t total_photons,
+                double* rays, float* colors)
+{
+    return guarded([&]() {
+        require(tracer != nullptr, "tracer is null");
+        require(light >= 0 && light < tracer->lightCount, "light index out of range");
+        require(n >= 0 && total_photons > 0, "bad photon counts");
+        if (n == 0)
+        {
+            return;
+        }
+        require(draws5 && rays && colors, "null buffer");
+        activate(tracer);
+        DeviceArray<double> dDraws, dRays;
+        DeviceArray<float> dColors;
+        dDraws.allocate(5 * n);
+        dRays.allocate(6 * n);
+        dColors.allocate(3 * n);
+        check(hipMemcpy(dDraws.ptr, draws5, 5 * n * sizeof(double), hipMemcpyHostToDevice), "hipMemcpy draws");
+        rtd::launchEmit(tracer->view, light, n, dDraws.ptr, total_photons, dRays.ptr, dColors.ptr, tracer->stream);
+        check(hipGetLastError(), "emit launch");
+        check(hipStreamSynchronize(tracer->stream), "hipStreamSynchronize");
+        check(hipMemcpy(rays, dRays.ptr, 6 * n * sizeof(double), hipMemcpyDeviceToHost), "hipMemcpy rays");
+        check(hipMemcpy(colors, dColors.ptr, 3 * n * sizeof(float), hipMemcpyDeviceToHost), "hipMemcpy colors");
+    });
+}
+
+#define RT_ROWS(name, kind, inCols, outType, outCols)                                                          \
+    int32_t name(int32_t device, int64_t n, const double* in, outType* out)                                     \
+    {                                                                                                           \
+        return guarded([&]() {                                                                                  \
+            runRows(device, n, in, sizeof(double) * (inCols) * n, out, sizeof(outType) * (outCols) * n,         \
+                    [&](unsigned char* dIn, unsigned char* dOut) {                                              \
+                        rtd::launchIntersect(kind, n, reinterpret_cast<const double*>(dIn), dOut, nullptr);     \
+                    });                                                                                         \
+        });                                                                                                     \
+    }
+
+RT_ROWS(rt_intersect_triangles, 0, 24, double, 8)
+RT_ROWS(rt_intersect_bounds, 1, 12, int32_t, 1)
+RT_ROWS(rt_intersect_spheres, 2, 10, double, 8)
+RT_ROWS(rt_intersect_quads, 3, 15, double, 20)
+RT_ROWS(rt_intersect_planes, 4, 10, double, 8)
+#undef RT_ROWS
+
+int32_t rt_bsdf_sample(int32_t device, int64_t n, const double* in14, double* out10)
+{
+    return guarded([&]() {
+        runRows(device, n, in14, sizeof(double) * 14 * n, out10, sizeof(double) * 10 * n,
+                [&](unsigned char* dIn, unsigned char* dOut) {
+                    rtd::launchBsdfSample(n, reinterpret_cast<const double*>(dIn), reinterpret_cast<double*>(dOut), nullptr);
+                });
+    });
+}
+
+int32_t rt_bsdf_evaluate(int32_t device, int64_t n, const double* in14, double* out4)
+{
+    return guarded([&]() {
+        runRows(device, n, in14, sizeof(double) * 14 * n, out4, sizeof(double) * 4 * n,
+                [&](unsigned char* dIn, unsigned char* dOut) {
+                    rtd::launchBsdfEvaluate(n, reinterpret_cast<const double*>(dIn), reinterpret_cast<double*>(dOut), nullptr);
+                });
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,991 @@
+// rt_device.h — device-side geometry, BSDF and emission routines (gfx950).
+//
+// Every routine reproduces, operation for operation, the arithmetic of the
+// reference function it cites (paths relative to the reference checkout), in FP64
+// for geometry and FP32 for energy, so that a photon's path is the same bits the
+// reference's CPU code would produce from the same inputs.  That requires:
+//   * -ffp-contract=off  (no FMA contraction anywhere; the watertight triangle
+//     test depends on individually rounded products, src/Ray.cpp:87-98);
+//   * IEEE division and square root (hipcc's default for f64);
+//   * the shared sin/cos/acos and Philox stream of include/rt_portable.h.
+// Vector semantics follow the reference's AVX path: dot = (x*x + y*y) + z*z, unary
+// minus = 0 - v, normalise = lane-wise divide by sqrt(dot) (src/Vector.cpp:233-267,
+// 340-347).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "rt_portable.h"
+#include "rt_scene.h"
+
+#define RT_DEV __device__ __forceinline__
+
+namespace rtd
+{
+
+constexpr double kPi = 3.14159265358979323846;
+constexpr double kPi2 = 3.14159265358979323846 * 2.0;
+constexpr double kEps = 2.220446049250313e-16;  // std::numeric_limits<double>::epsilon()
+constexpr double kMaxDouble = 1.7976931348623157e308;
+
+struct Vec
+{
+    double x, y, z;
+};
+
+RT_DEV Vec mk(double x, double y, double z) { return Vec{x, y, z}; }
+RT_DEV Vec operator+(const Vec& a, const Vec& b) { return Vec{a.x + b.x, a.y + b.y, a.z + b.z}; }
+RT_DEV Vec operator-(const Vec& a, const Vec& b) { return Vec{a.x - b.x, a.y - b.y, a.z - b.z}; }
+RT_DEV Vec neg(const Vec& v) { return Vec{0.0 - v.x, 0.0 - v.y, 0.0 - v.z}; }
+RT_DEV Vec operator*(const Vec& a, double s) { return Vec{a.x * s, a.y * s, a.z * s}; }
+RT_DEV Vec operator*(double s, const Vec& a) { return Vec{s * a.x, s * a.y, s * a.z}; }
+RT_DEV Vec operator/(const Vec& a, double s) { return Vec{a.x / s, a.y / s, a.z / s}; }
+RT_DEV double dot(const Vec& a, const Vec& b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+RT_DEV double magnitude(const Vec& a) { return __builtin_sqrt(dot(a, a)); }
+RT_DEV Vec normalized(const Vec& a)
+{
+    const double root = __builtin_sqrt(dot(a, a));
+    return Vec{a.x / root, a.y / root, a.z / root};
+}
+RT_DEV Vec cross(const Vec& a, const Vec& b)
+{
+    return Vec{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+RT_DEV Vec reflected(const Vec& i, const Vec& n)  // src/Vector.cpp:298-312
+{
+    const double dot2 = 2 * dot(i, n);
+    return Vec{i.x - dot2 * n.x, i.y - dot2 * n.y, i.z - dot2 * n.z};
+}
+RT_DEV double axisOf(const Vec& v, int axis) { return axis == 0 ? v.x : (axis == 1 ? v.y : v.z); }
+RT_DEV double dmin(double a, double b) { return b < a ? b : a; }  // std::min
+RT_DEV double dmax(double a, double b) { return a < b ? b : a; }  // std::max
+RT_DEV double dabs(double a) { return __builtin_fabs(a); }
+
+struct Quat
+{
+    double x, y, z, w;
+};
+
+// src/Quaternion.cpp:88-109
+RT_DEV Quat qmul(const Quat& l, const Quat& r)
+{
+    return Quat{l.w * r.x + l.x * r.w + l.y * r.z - l.z * r.y, l.w * r.y + l.y * r.w + l.z * r.x - l.x * r.z,
+                l.w * r.z + l.z * r.w + l.x * r.y - l.y * r.x, l.w * r.w - l.x * r.x - l.y * r.y - l.z * r.z};
+}
+RT_DEV Vec rotate(const Quat& q, const Vec& v)
+{
+    const Quat p{v.x, v.y, v.z, 0.0};
+    const Quat c{-q.x, -q.y, -q.z, q.w};
+    const Quat r = qmul(qmul(q, p), c);
+    return Vec{r.x, r.y, r.z};
+}
+
+struct Color
+{
+    float r, g, b;
+};
+RT_DEV Color operator*(const Color& a, float s) { return Color{a.r * s, a.g * s, a.b * s}; }
+RT_DEV Color operator*(const Color& a, const Color& b) { return Color{a.r * b.r, a.g * b.g, a.b * b.b}; }
+RT_DEV float brightness(const Color& c) { return c.r + c.g + c.b; }
+
+// ------------------------------------------------------------------ flattened scene
+// One node of a mesh's tree, in the reference's visiting order (node page, left
+// subtree, right subtree — src/Tree.cpp:207-237).  `skip` is the index of the next
+// node in that order once this node's subtree is left out.
+struct Node
+{
+    double bmin[3];
+    double bmax[3];
+    int32_t skip;
+    int32_t triStart;  // into the mesh's page-ordered triangle arrays
+    int32_t triCount;
+    int32_t pad;
+};
+static_assert(sizeof(Node) == 64, "Node must be one 64-byte line");
+
+struct Volume
+{
+    int32_t type, material, nodeBase, nodeCount;
+    int64_t triBase;  // first triangle of the mesh in the page-ordered arrays
+    double pos[3];
+    Quat rot, inv;    // rotation and Quaternion::inverse() of it (src/Quaternion.cpp:49-52)
+    double param[18];
+};
+
+struct Material
+{
+    int32_t type, pad;
+    float color[3];
+    float pad2;
+    double alpha, ior;
+};
+
+struct Light
+{
+    int32_t type, shape;
+    double pos[3];
+    Quat rot;
+    double forward[3];  // rot * unitZ
+    float color[3];
+    float pad;
+    double flux, innerRadius, maxAngle, radius, width, height;
+};
+
+struct Camera
+{
+    double pos[3];
+    double right[3], up[3], forward[3];
+    double aspect, halfHeight, tanPixelHalfAngle;
+    int32_t width, height, bounceFilter, lightFilter;
+    float windowStart, windowEnd;
+    float* buffer;  // [h][w][3]
+};
+
+struct SceneView
+{
+    const Volume* volumes;
+    const Node* nodes;
+    const double* triPos;  // [9 * T] page order
+    const double* triNrm;  // [9 * T] page order
+    const int32_t* triId;  // page order -> index within the mesh (load order)
+    const Material* materials;
+    const Light* lights;
+    Camera* cameras;
+    int32_t volumeCount, lightCount, cameraCount, bounceThreshold;
+    double terminationThreshold;
+    double splatLuminanceClamp;
+    uint64_t photonsPerLight;
+    uint32_t seed;
+    float windowStart, windowEnd;  // primary camera's exposure window
+    int32_t hasCamera;
+};
+
+struct Ray
+{
+    Vec o, d;
+};
+
+struct Hit
+{
+    Vec position, normal;
+    double distance;
+    int32_t material, volume, triangle;
+};
+
+// ------------------------------------------------------------------ intersectors
+// src/Ray.cpp:16-57.  Returns the entry parameter through *entry (>= 0).
+RT_DEV bool rayIntersectsBounds(const Ray& ray, const double* bmin, const double* bmax, double* entry)
+{
+    double tmin = 0.0;
+    double tmax = kMaxDouble;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+    {
+        const double origin = axisOf(ray.o, i);
+        const double direction = axisOf(ray.d, i);
+        if (dabs(direction) < kEps)
+        {
+            if (origin < bmin[i] || origin > bmax[i])
+            {
+                return false;
+            }
+        }
+        else
+        {
+            const double ood = 1.0 / direction;
+            double t1 = (bmin[i] - origin) * ood;
+            double t2 = (bmax[i] - origin) * ood;
+            if (t1 > t2)
+            {
+                const double t = t1;
+                t1 = t2;
+                t2 = t;
+            }
+            tmin = dmax(tmin, t1);
+            tmax = dmin(tmax, t2);
+            if (tmin > tmax)
+            {
+                return false;
+            }
+        }
+    }
+    *entry = tmin;
+    return true;
+}
+
+// Per-ray constants of the slab and watertight tests (they depend on the ray only).
+struct RayPrep
+{
+    double ood[3];       // 1 / direction per axis (unused where parallel[i])
+    bool parallel[3];    // |direction| < epsilon
+    int kx, ky, kz;      // watertight axis permutation, src/Ray.cpp:100-139
+    double sx, sy, sz;   // shear constants, :141-147
+};
+
+RT_DEV RayPrep prepareRay(const Ray& ray)
+{
+    RayPrep p;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+    {
+        const double d = axisOf(ray.d, i);
+        p.parallel[i] = dabs(d) < kEps;
+        p.ood[i] = 1.0 / d;
+    }
+    const double adx = dabs(ray.d.x), ady = dabs(ray.d.y), adz = dabs(ray.d.z);
+    int kz = 2;
+    if (adx > ady && adx > adz)
+    {
+        kz = 0;
+    }
+    else if (ady > adz)
+    {
+        kz = 1;
+    }
+    int kx = kz + 1;
+    if (kx == 3) kx = 0;
+    int ky = kx + 1;
+    if (ky == 3) ky = 0;
+    if (axisOf(ray.d, kz) < 0.0)
+    {
+        const int t = kx;
+        kx = ky;
+        ky = t;
+    }
+    p.kx = kx;
+    p.ky = ky;
+    p.kz = kz;
+    const double dkx = axisOf(ray.d, kx), dky = axisOf(ray.d, ky), dkz = axisOf(ray.d, kz);
+    p.sx = dkx / dkz;
+    p.sy = dky / dkz;
+    p.sz = 1.0 / dkz;
+    return p;
+}
+
+// Slab test with the per-ray reciprocals hoisted; identical results to
+// rayIntersectsBounds (the reciprocal is the same correctly rounded quotient).
+RT_DEV bool slabTest(const Ray& ray, const RayPrep& p, const double* bmin, const double* bmax, double* entry)
+{
+    double tmin = 0.0;
+    double tmax = kMaxDouble;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+    {
+        const double origin = axisOf(ray.o, i);
+        if (p.parallel[i])
+        {
+            if (origin < bmin[i] || origin > bmax[i])
+            {
+                return false;
+            }
+        }
+        else
+        {
+            double t1 = (bmin[i] - origin) * p.ood[i];
+            double t2 = (bmax[i] - origin) * p.ood[i];
+            if (t1 > t2)
+            {
+                const double t = t1;
+                t1 = t2;
+                t2 = t;
+            }
+            tmin = dmax(tmin, t1);
+            tmax = dmin(tmax, t2);
+            if (tmin > tmax)
+            {
+                return false;
+            }
+        }
+    }
+    *entry = tmin;
+    return true;
+}
+
+RT_DEV bool edgeAccept(double value, double ex, double ey)  // src/Ray.cpp:190-202
+{
+    if (value > 0.0) return true;
+    if (value < 0.0) return false;
+    return (ey < 0.0) || (ey == 0.0 && ex < 0.0);
+}
+
+// Watertight ray/triangle test, src/Ray.cpp:85-247.  On a hit writes the barycentric
+// weights, the reconstructed position and the Euclidean distance.
+RT_DEV bool rayIntersectsTriangle(const Ray& ray, const RayPrep& p, const double* tp, double* bary, Vec* position,
+                                  double* distance)
+{
+    const Vec a = mk(tp[0], tp[1], tp[2]), b = mk(tp[3], tp[4], tp[5]), c = mk(tp[6], tp[7], tp[8]);
+    const Vec vA = a - ray.o, vB = b - ray.o, vC = c - ray.o;
+    const double aKz = axisOf(vA, p.kz), bKz = axisOf(vB, p.kz), cKz = axisOf(vC, p.kz);
+    const double ax = axisOf(vA, p.kx) - p.sx * aKz, ay = axisOf(vA, p.ky) - p.sy * aKz;
+    const double bx = axisOf(vB, p.kx) - p.sx * bKz, by = axisOf(vB, p.ky) - p.sy * bKz;
+    const double cx = axisOf(vC, p.kx) - p.sx * cKz, cy = axisOf(vC, p.ky) - p.sy * cKz;
+
+    const double u = cx * by - cy * bx;
+    const double v = ax * cy - ay * cx;
+    const double w = bx * ay - by * ax;
+
+    if (!edgeAccept(w, bx - ax, by - ay) || !edgeAccept(u, cx - bx, cy - by) || !edgeAccept(v, ax - cx, ay - cy))
+    {
+        return false;
+    }
+    const double det = u + v + w;
+    if (det <= 0.0)
+    {
+        return false;
+    }
+    const double az = p.sz * aKz, bz = p.sz * bKz, cz = p.sz * cKz;
+    const double tScaled = u * az + v * bz + w * cz;
+    if (tScaled <= 0.0)
+    {
+        return false;
+    }
+    const double invDet = 1.0 / det;
+    const double ca = u * invDet, cb = v * invDet, cc = w * invDet;
+    const Vec pos = (ca * a) + (cb * b) + (cc * c);  // src/Triangle.cpp:42-45
+    bary[0] = ca;
+    bary[1] = cb;
+    bary[2] = cc;
+    *position = pos;
+    *distance = magnitude(pos - ray.o);
+    return true;
+}
+
+RT_DEV Vec triangleNormal(const double* tn, const double* bary)  // src/Triangle.cpp:47-50, src/Ray.cpp:243
+{
+    const Vec aN = mk(tn[0], tn[1], tn[2]), bN = mk(tn[3], tn[4], tn[5]), cN = mk(tn[6], tn[7], tn[8]);
+    return normalized((bary[0] * aN) + (bary[1] * bN) + (bary[2] * cN));
+}
+
+// src/Ray.cpp:249-271
+RT_DEV bool rayIntersectsPlane(const Ray& ray, const Vec& normal, double planeDot, Vec* position, Vec* outNormal,
+                               double* distance)
+{
+    const double d = dot(normal, ray.d);
+    if (dabs(d) <= kEps)
+    {
+        return false;
+    }
+    const double t = (planeDot - dot(normal, ray.o)) / d;
+    if (t < 0.0)
+    {
+        return false;
+    }
+    *position = ray.o + (t * ray.d);
+    *outNormal = normal;
+    *distance = magnitude(*position - ray.o);
+    return true;
+}
+
+// src/Ray.cpp:273-327
+RT_DEV bool rayIntersectsSphere(const Ray& ray, const Vec& center, double radius, Vec* position, Vec* normal,
+                                double* distance)
+{
+    const Vec oc = ray.o - center;
+    const double a = dot(ray.d, ray.d);
+    if (dabs(a) <= kEps)
+    {
+        return false;
+    }
+    const double b = 2.0 * dot(oc, ray.d);
+    const double c = dot(oc, oc) - radius * radius;
+    const double discriminant = b * b - 4.0 * a * c;
+    if (discriminant < 0.0)
+    {
+        return false;
+    }
+    const double sqrtDiscriminant = __builtin_sqrt(discriminant);
+    const double inv = 1.0 / (2.0 * a);
+    double t = (-b - sqrtDiscriminant) * inv;
+    if (t <= 1e-6)
+    {
+        t = (-b + sqrtDiscriminant) * inv;
+        if (t <= 1e-6)
+        {
+            return false;
+        }
+    }
+    *position = ray.o + (t * ray.d);
+    *normal = normalized(*position - center);
+    *distance = magnitude(*position - ray.o);
+    return true;
+}
+
+// src/Ray.cpp:329-375; q = origin edgeU edgeV normal invU invV
+RT_DEV bool rayIntersectsQuad(const Ray& ray, const double* q, Vec* position, Vec* normal, double* distance, Vec* uv)
+{
+    const Vec qo = mk(q[0], q[1], q[2]), qn = mk(q[9], q[10], q[11]);
+    const Vec invU = mk(q[12], q[13], q[14]), invV = mk(q[15], q[16], q[17]);
+    const double denom = dot(qn, ray.d);
+    if (dabs(denom) <= kEps)
+    {
+        return false;
+    }
+    const Vec toOrigin = qo - ray.o;
+    const double t = dot(toOrigin, qn) / denom;
+    if (t <= 1e-9)
+    {
+        return false;
+    }
+    const Vec pos = ray.o + (t * ray.d);
+    const Vec local = pos - qo;
+    const double u = dot(local, invU), v = dot(local, invV);
+    if (u < 0.0 || u > 1.0 || v < 0.0 || v > 1.0)
+    {
+        return false;
+    }
+    *position = pos;
+    *normal = denom > 0.0 ? neg(qn) : qn;
+    *uv = mk(u, v, 0.0);
+    *distance = magnitude(pos - ray.o);
+    return true;
+}
+
+// Quad::update, src/Quad.cpp:21-48: fills q[9..17] from q[0..8].
+RT_DEV void quadUpdate(double* q)
+{
+    const Vec eu = mk(q[3], q[4], q[5]), ev = mk(q[6], q[7], q[8]);
+    const Vec n = normalized(cross(eu, ev));
+    const double g11 = dot(eu, eu), g22 = dot(ev, ev), g12 = dot(eu, ev);
+    const double det = g11 * g22 - g12 * g12;
+    Vec iu = mk(0, 0, 0), iv = mk(0, 0, 0);
+    if (det != 0.0)
+    {
+        const double invDet = 1.0 / det;
+        iu = (g22 * eu - g12 * ev) * invDet;
+        iv = (g11 * ev - g12 * eu) * invDet;
+    }
+    q[9] = n.x; q[10] = n.y; q[11] = n.z;
+    q[12] = iu.x; q[13] = iu.y; q[14] = iu.z;
+    q[15] = iv.x; q[16] = iv.y; q[17] = iv.z;
+}
+
+// ------------------------------------------------------------------ scene cast
+// Closest hit of one mesh, equal to Tree::castRay's exhaustive minimum
+// (src/Tree.cpp:133-152,207-237): nodes are visited in the reference's order and a
+// candidate replaces the best only when strictly closer, so the first-found wins
+// exact ties as there.  A subtree is additionally skipped when the ray enters its
+// box farther than the best distance so far (with a 1e-9 relative margin for the
+// rounding between the box parameter and the reconstructed Euclidean distance):
+// such a subtree cannot hold a strictly closer hit, so the result is unchanged.
+RT_DEV bool castMesh(const SceneView& s, const Volume& vol, const Ray& ray, const RayPrep& prep, double* bary,
+                     Vec* position, double* distance, int32_t* triSlot)
+{
+    const Node* nodes = s.nodes + vol.nodeBase;
+    const double* triPos = s.triPos + 9 * vol.triBase;
+    const double dlen = magnitude(ray.d);
+    bool found = false;
+    double best = kMaxDouble;
+    int32_t i = 0;
+    const int32_t count = vol.nodeCount;
+    while (i < count)
+    {
+        const Node& node = nodes[i];
+        double entry;
+        bool descend = slabTest(ray, prep, node.bmin, node.bmax, &entry);
+        if (descend && found && entry * dlen > best * (1.0 + 1e-9))
+        {
+            descend = false;
+        }
+        if (descend)
+        {
+            const int32_t t0 = node.triStart, t1 = t0 + node.triCount;
+            for (int32_t t = t0; t < t1; ++t)
+            {
+                double b3[3], d;
+                Vec pos;
+                if (rayIntersectsTriangle(ray, prep, triPos + 9 * t, b3, &pos, &d))
+                {
+                    if (!found || d < best)
+                    {
+                        found = true;
+                        best = d;
+                        bary[0] = b3[0];
+                        bary[1] = b3[1];
+                        bary[2] = b3[2];
+                        *position = pos;
+                        *triSlot = t;
+                    }
+                }
+            }
+            i += 1;
+        }
+        else
+        {
+            i = node.skip;
+        }
+    }
+    *distance = best;
+    return found;
+}
+
+// Nearest valid hit over all volumes: Volume::castRayAt for each volume in object
+// order (src/Volume.cpp:34-63), then the strict-minimum selection with the self-hit
+// floor applied AFTER each volume's own closest hit was chosen
+// (src/Worker.cpp:556-567).  When `needSurface` is false only the distance is
+// produced (occlusion test, src/Worker.cpp:314-333).
+RT_DEV bool castScene(const SceneView& s, const Ray& ray, double selfHit, bool needSurface, Hit* out)
+{
+    double minDistance = kMaxDouble;
+    bool valid = false;
+    Vec bestPos = mk(0, 0, 0), bestNrm = mk(0, 0, 0);
+    int32_t bestVolume = -1, bestTri = -1;
+    for (int32_t v = 0; v < s.volumeCount; ++v)
+    {
+        const Volume& vol = s.volumes[v];
+        const Vec vpos = mk(vol.pos[0], vol.pos[1], vol.pos[2]);
+        Ray local;
+        local.o = rotate(vol.inv, ray.o - vpos);
+        local.d = rotate(vol.inv, ray.d);
+        Vec pos, nrm = mk(0, 0, 0);
+        double dist;
+        bool found = false;
+        int32_t tri = -1;
+        if (vol.type == RT_VOLUME_MESH)
+        {
+            const RayPrep prep = prepareRay(local);
+            double bary[3];
+            int32_t slot = 0;
+            found = castMesh(s, vol, local, prep, bary, &pos, &dist, &slot);
+            if (found && dist < minDistance && dist > selfHit)
+            {
+                if (needSurface)
+                {
+                    nrm = triangleNormal(s.triNrm + 9 * (vol.triBase + slot), bary);
+                    tri = s.triId[vol.triBase + slot];
+                }
+            }
+            else
+            {
+                found = false;
+            }
+        }
+        else if (vol.type == RT_VOLUME_SPHERE)
+        {
+            found = rayIntersectsSphere(local, mk(vol.param[0], vol.param[1], vol.param[2]), vol.param[3], &pos, &nrm,
+                                        &dist);
+        }
+        else if (vol.type == RT_VOLUME_QUAD)
+        {
+            Vec uv;
+            found = rayIntersectsQuad(local, vol.param, &pos, &nrm, &dist, &uv);
+        }
+        else
+        {
+            found = rayIntersectsPlane(local, mk(vol.param[0], vol.param[1], vol.param[2]), vol.param[3], &pos, &nrm,
+                                       &dist);
+        }
+        if (found && dist < minDistance && dist > selfHit)
+        {
+            valid = true;
+            minDistance = dist;
+            bestPos = pos;
+            bestNrm = nrm;
+            bestVolume = v;
+            bestTri = tri;
+        }
+    }
+    out->distance = minDistance;
+    if (valid && needSurface)
+    {
+        const Volume& vol = s.volumes[bestVolume];
+        out->position = mk(vol.pos[0], vol.pos[1], vol.pos[2]) + rotate(vol.rot, bestPos);
+        out->normal = rotate(vol.rot, bestNrm);
+        out->material = vol.material;
+        out->volume = bestVolume;
+        out->triangle = bestTri;
+    }
+    return valid;
+}
+
+// ------------------------------------------------------------------ random draws
+// Draws come either from the per-photon Philox stream or from an explicit tape
+// (function-level entry points).
+struct Rng
+{
+    rt_philox_state philox;
+    const double* tape;
+    int next;
+    uint32_t seed;
+    RT_DEV void begin(uint32_t light, uint64_t photon, uint32_t stage)
+    {
+        if (!tape)
+        {
+            rt_philox_begin(&philox, seed, light, photon, stage);
+        }
+    }
+    RT_DEV double value(double scale = 1.0)
+    {
+        if (tape)
+        {
+            return tape[next++] * scale;
+        }
+        return rt_philox_next(&philox) * scale;
+    }
+};
+
+// ------------------------------------------------------------------ BSDFs
+struct BSDFSample
+{
+    Vec direction;
+    Color weight;
+    double pdf;
+    bool isDelta, valid;
+};
+
+RT_DEV bool materialIsDelta(int32_t type) { return type == RT_MATERIAL_MIRROR || type == RT_MATERIAL_DIELECTRIC; }
+
+// src/LambertianMaterial.cpp:13-25
+RT_DEV void buildBasis(const Vec& n, Vec* tangent, Vec* bitangent)
+{
+    if (n.z < -0.9999999)
+    {
+        *tangent = mk(0.0, -1.0, 0.0);
+        *bitangent = mk(-1.0, 0.0, 0.0);
+        return;
+    }
+    const double a = 1.0 / (1.0 + n.z);
+    const double b = -n.x * n.y * a;
+    *tangent = mk(1.0 - n.x * n.x * a, b, -n.x);
+    *bitangent = mk(b, 1.0 - n.y * n.y * a, -n.y);
+}
+
+RT_DEV double clamp01(double v) { return v < 0.0 ? 0.0 : (1.0 < v ? 1.0 : v); }  // std::clamp(v, 0, 1)
+
+// src/MicrofacetMaterial.cpp:29-77
+RT_DEV double ggxD(double cosThetaH, double alpha)
+{
+    if (cosThetaH <= 0.0) return 0.0;
+    const double a2 = alpha * alpha;
+    const double cos2 = cosThetaH * cosThetaH;
+    const double denom = (a2 - 1.0) * cos2 + 1.0;
+    return a2 / (kPi * denom * denom);
+}
+RT_DEV double smithLambda(double cosTheta, double alpha)
+{
+    if (cosTheta >= 1.0 || cosTheta <= 0.0) return 0.0;
+    const double cos2 = cosTheta * cosTheta;
+    const double sin2 = dmax(0.0, 1.0 - cos2);
+    const double tan2 = sin2 / cos2;
+    return 0.5 * (__builtin_sqrt(1.0 + alpha * alpha * tan2) - 1.0);
+}
+RT_DEV double smithG1(double cosTheta, double alpha) { return 1.0 / (1.0 + smithLambda(cosTheta, alpha)); }
+RT_DEV Color schlickFresnel(const float* F0, double cosTheta)
+{
+    const double t = dmax(0.0, 1.0 - cosTheta);
+    const double t5 = t * t * t * t * t;
+    return Color{static_cast<float>(F0[0] + (1.0 - F0[0]) * t5), static_cast<float>(F0[1] + (1.0 - F0[1]) * t5),
+                 static_cast<float>(F0[2] + (1.0 - F0[2]) * t5)};
+}
+
+// Material::sample for the four materials: src/LambertianMaterial.cpp:52-75,
+// src/MirrorMaterial.cpp:15-27, src/DielectricMaterial.cpp:30-136,
+// src/MicrofacetMaterial.cpp:93-123,141-214.
+RT_DEV BSDFSample sampleMaterial(const Material& m, const Vec& incident, const Vec& normal, Rng& rng)
+{
+    BSDFSample s;
+    s.direction = mk(0, 0, 0);
+    s.weight = Color{1.0f, 1.0f, 1.0f};
+    s.pdf = 0.0;
+    s.isDelta = false;
+    s.valid = false;
+    const Color albedo{m.color[0], m.color[1], m.color[2]};
+    if (m.type == RT_MATERIAL_LAMBERTIAN)
+    {
+        Vec tangent, bitangent;
+        buildBasis(normal, &tangent, &bitangent);
+        const double u1 = rng.value();
+        const double u2 = rng.value();
+        const double r = __builtin_sqrt(u1);
+        const double phi = kPi2 * u2;
+        double sn, cs;
+        rt_sincos(phi, &sn, &cs);
+        const Vec local = mk(r * cs, r * sn, __builtin_sqrt(dmax(0.0, 1.0 - u1)));
+        Vec world = tangent * local.x + bitangent * local.y + normal * local.z;
+        world = normalized(world);
+        const double cosTheta = dmax(0.0, dot(world, normal));
+        s.direction = world;
+        s.weight = albedo;
+        s.pdf = cosTheta / kPi;
+        s.valid = cosTheta > 0.0;
+        return s;
+    }
+    if (m.type == RT_MATERIAL_MIRROR)
+    {
+        s.direction = normalized(reflected(incident, normal));
+        s.weight = albedo;
+        s.pdf = 1.0;
+        s.isDelta = true;
+        s.valid = dot(s.direction, normal) > 0.0;
+        return s;
+    }
+    if (m.type == RT_MATERIAL_DIELECTRIC)
+    {
+        const Vec dir = normalized(incident);
+        Vec n = normalized(normal);
+        double cosI = dot(dir, n);
+        double n1, n2;
+        if (cosI < 0.0)
+        {
+            n1 = 1.0;
+            n2 = m.ior;
+            cosI = -cosI;
+        }
+        else
+        {
+            n = neg(n);
+            n1 = m.ior;
+            n2 = 1.0;
+        }
+        const Vec reflectDir = normalized(reflected(dir, n));
+        Vec refractDir = reflectDir;
+        bool tir = false;
+        double reflectance = 1.0;
+        const double eta = n1 / n2;
+        const double sinT2 = eta * eta * (1.0 - cosI * cosI);
+        if (sinT2 > 1.0)
+        {
+            tir = true;
+        }
+        else
+        {
+            const double cosT = __builtin_sqrt(dmax(0.0, 1.0 - sinT2));
+            refractDir = normalized(dir * eta + n * (eta * cosI - cosT));
+            const double cosForFresnel = (n1 <= n2) ? cosI : cosT;
+            double r0 = (n1 - n2) / (n1 + n2);
+            r0 = r0 * r0;
+            const double mm = clamp01(1.0 - cosForFresnel);
+            const double m5 = mm * mm * mm * mm * mm;
+            reflectance = clamp01(r0 + (1.0 - r0) * m5);
+        }
+        s.isDelta = true;
+        s.pdf = 1.0;
+        const double xi = rng.value();
+        s.direction = (tir || xi < reflectance) ? reflectDir : refractDir;
+        s.weight = albedo;
+        s.valid = dot(s.direction, s.direction) > 0.5;
+        return s;
+    }
+    // Microfacet (GGX, VNDF sampling)
+    const Vec wi = neg(incident);
+    const double cosThetaI = dot(wi, normal);
+    if (cosThetaI <= 0.0)
+    {
+        return s;
+    }
+    Vec tangent, bitangent;
+    buildBasis(normal, &tangent, &bitangent);
+    const Vec Ve = mk(dot(wi, tangent), dot(wi, bitangent), cosThetaI);
+    const double u1 = rng.value();
+    const double u2 = rng.value();
+    const double alpha = m.alpha;
+    Vec hLocal;
+    {
+        const Vec Vh = normalized(mk(alpha * Ve.x, alpha * Ve.y, Ve.z));
+        const double lensq = Vh.x * Vh.x + Vh.y * Vh.y;
+        const Vec T1 = (lensq > 0.0) ? mk(-Vh.y, Vh.x, 0.0) * (1.0 / __builtin_sqrt(lensq)) : mk(1.0, 0.0, 0.0);
+        const Vec T2 = cross(Vh, T1);
+        const double r = __builtin_sqrt(u1);
+        const double phi = kPi2 * u2;
+        double sn, cs;
+        rt_sincos(phi, &sn, &cs);
+        const double t1 = r * cs;
+        double t2 = r * sn;
+        const double sh = 0.5 * (1.0 + Vh.z);
+        t2 = (1.0 - sh) * __builtin_sqrt(dmax(0.0, 1.0 - t1 * t1)) + sh * t2;
+        const double t3 = __builtin_sqrt(dmax(0.0, 1.0 - t1 * t1 - t2 * t2));
+        const Vec Nh = T1 * t1 + T2 * t2 + Vh * t3;
+        hLocal = normalized(mk(alpha * Nh.x, alpha * Nh.y, dmax(0.0, Nh.z)));
+    }
+    Vec wh = tangent * hLocal.x + bitangent * hLocal.y + normal * hLocal.z;
+    wh = normalized(wh);
+    const double wiDotWh = dot(wi, wh);
+    if (wiDotWh <= 0.0)
+    {
+        return s;
+    }
+    Vec wo = wh * (2.0 * wiDotWh) - wi;
+    wo = normalized(wo);
+    const double cosThetaO = dot(wo, normal);
+    const double cosThetaH = dot(wh, normal);
+    if (cosThetaO <= 0.0 || cosThetaH <= 0.0)
+    {
+        return s;
+    }
+    const double D = ggxD(cosThetaH, alpha);
+    const double G1i = smithG1(cosThetaI, alpha);
+    const double G2 = smithG1(cosThetaI, alpha) * smithG1(cosThetaO, alpha);
+    const Color F = schlickFresnel(m.color, wiDotWh);
+    const double weightScalar = (G1i > 0.0) ? (G2 / G1i) : 0.0;
+    s.direction = wo;
+    s.weight = F * static_cast<float>(weightScalar);
+    s.pdf = (G1i * D) / (4.0 * cosThetaI);
+    s.valid = true;
+    return s;
+}
+
+// Material::evaluate: src/LambertianMaterial.cpp:94-113, src/MicrofacetMaterial.cpp:258-286;
+// delta materials are black.
+RT_DEV Color evaluateMaterial(const Material& m, const Vec& wi, const Vec& wo, const Vec& normal)
+{
+    const Color black{0.0f, 0.0f, 0.0f};
+    if (m.type == RT_MATERIAL_LAMBERTIAN)
+    {
+        if (dot(wi, normal) <= 0.0 || dot(wo, normal) <= 0.0)
+        {
+            return black;
+        }
+        return Color{m.color[0], m.color[1], m.color[2]} * static_cast<float>(1.0 / kPi);
+    }
+    if (m.type == RT_MATERIAL_MICROFACET)
+    {
+        const double ci = dot(wi, normal), co = dot(wo, normal);
+        if (ci <= 0.0 || co <= 0.0) return black;
+        Vec wh = wi + wo;
+        if (dot(wh, wh) < 1e-20) return black;
+        wh = normalized(wh);
+        const double ch = dot(wh, normal);
+        if (ch <= 0.0) return black;
+        const double D = ggxD(ch, m.alpha);
+        const double G2 = smithG1(ci, m.alpha) * smithG1(co, m.alpha);
+        const Color F = schlickFresnel(m.color, dmax(0.0, dot(wi, wh)));
+        const double scalar = (D * G2) / (4.0 * ci * co);
+        return F * static_cast<float>(scalar);
+    }
+    return black;
+}
+
+// Material::pdf: src/LambertianMaterial.cpp:115-123, src/MicrofacetMaterial.cpp:297-333
+RT_DEV double pdfMaterial(const Material& m, const Vec& wi, const Vec& wo, const Vec& normal)
+{
+    if (m.type == RT_MATERIAL_LAMBERTIAN)
+    {
+        const double c = dot(wo, normal);
+        return c <= 0.0 ? 0.0 : c / kPi;
+    }
+    if (m.type == RT_MATERIAL_MICROFACET)
+    {
+        const double ci = dot(wi, normal), co = dot(wo, normal);
+        if (ci <= 0.0 || co <= 0.0) return 0.0;
+        Vec wh = wi + wo;
+        if (dot(wh, wh) < 1e-20) return 0.0;
+        wh = normalized(wh);
+        const double ch = dot(wh, normal);
+        if (ch <= 0.0) return 0.0;
+        if (dot(wi, wh) <= 0.0) return 0.0;
+        return (smithG1(ci, m.alpha) * ggxD(ch, m.alpha)) / (4.0 * ci);
+    }
+    return 0.0;
+}
+
+// ------------------------------------------------------------------ emission
+// src/Vector.cpp:319-329
+RT_DEV Vec randomSphere(Rng& rng)
+{
+    const double theta = 2 * kPi * rng.value();
+    const double phi = rt_acos(1.0 - 2.0 * rng.value());
+    double sp, cp, st, ct;
+    rt_sincos(phi, &sp, &cp);
+    rt_sincos(theta, &st, &ct);
+    return mk(sp * ct * 1.0, sp * st * 1.0, cp * 1.0);
+}
+
+// src/Vector.cpp:314-317; the reference binary draws the magnitude before the sphere
+// direction (operand evaluation order of g++ on x86-64, confirmed by the emission
+// fixtures).
+RT_DEV Vec randomVector(Rng& rng, double magnitude)
+{
+    const double scale = rng.value(magnitude);
+    const Vec sphere = randomSphere(rng);
+    return sphere * scale;
+}
+
+// Light::emit: src/OmniLight.cpp:23-44, src/SpotLight.cpp:50-70 with
+// src/AngleGenerator.cpp:8-36, src/ParallelLight.cpp:26-47, src/AreaLight.cpp:106-155.
+RT_DEV Ray emitRay(const Light& l, Rng& rng)
+{
+    const Vec lpos = mk(l.pos[0], l.pos[1], l.pos[2]);
+    const Vec forward = mk(l.forward[0], l.forward[1], l.forward[2]);
+    Ray ray;
+    if (l.type == RT_LIGHT_OMNI)
+    {
+        const Vec direction = randomSphere(rng);
+        Vec offset = mk(0, 0, 0);
+        if (l.innerRadius > 0)
+        {
+            offset = randomVector(rng, l.innerRadius);
+        }
+        ray.o = lpos + offset;
+        ray.d = direction;
+        return ray;
+    }
+    if (l.type == RT_LIGHT_SPOT)
+    {
+        const Vec center = forward;
+        const double theta = rng.value(kPi2);
+        double value = rng.value(1.0);
+        value = dmin(dmax(-1.0, value), 1.0);
+        const double angle = value * l.maxAngle;  // pow(value, linearity = 1) == value
+        const bool useZ = dabs(dot(mk(0, 1, 0), center)) > 0.9;
+        const Vec crossAxis = useZ ? mk(0, 0, 1) : mk(0, 1, 0);
+        double sa, ca, sh, ch;
+        rt_sincos(angle, &sa, &ca);
+        rt_sincos(theta / 2.0, &sh, &ch);
+        Vec offset = cross(center, crossAxis) * sa;
+        const Quat rotation{center.x * sh, center.y * sh, center.z * sh, ch};
+        offset = rotate(rotation, offset);
+        const Vec offsetDirection = (center * ca) + offset;
+        Vec origin = mk(0, 0, 0);
+        if (l.innerRadius > 0)
+        {
+            origin = randomVector(rng, l.innerRadius);
+        }
+        ray.o = lpos + origin;
+        ray.d = offsetDirection;
+        return ray;
+    }
+    if (l.type == RT_LIGHT_PARALLEL)
+    {
+        Vec offset = mk(0, 0, 0);
+        if (l.radius > 0)
+        {
+            offset = randomVector(rng, l.radius);
+            offset = offset - (dot(offset, forward) * forward);
+            offset = normalized(offset) * (__builtin_sqrt(magnitude(offset) / l.radius) * l.radius);
+        }
+        ray.o = lpos + offset;
+        ray.d = forward;
+        return ray;
+    }
+    const Vec right = rotate(l.rot, mk(1, 0, 0));
+    const Vec up = rotate(l.rot, mk(0, 1, 0));
+    const Vec normal = rotate(l.rot, mk(0, 0, 1));
+    Vec origin;
+    if (l.shape == 1)
+    {
+        const double theta = rng.value(kPi2);
+        const double r = l.radius * __builtin_sqrt(rng.value(1.0));
+        double st, ct;
+        rt_sincos(theta, &st, &ct);
+        origin = lpos + (right * (r * ct)) + (up * (r * st));
+    }
+    else
+    {
+        const double u = (rng.value(1.0) - 0.5) * l.width;
+        const double v = (rng.value(1.0) - 0.5) * l.height;
+        origin = lpos + (right * u) + (up * v);
+    }
+    const double diskTheta = rng.value(kPi2);
+    const double diskR = __builtin_sqrt(rng.value(1.0));
+    double sd, cd;
+    rt_sincos(diskTheta, &sd, &cd);
+    const double dx = diskR * cd;
+    const double dy = diskR * sd;
+    const double dz = __builtin_sqrt(dmax(0.0, 1.0 - (dx * dx) - (dy * dy)));
+    Vec direction = (right * dx) + (up * dy) + (normal * dz);
+    direction = normalized(direction);
+    ray.o = origin;
+    ray.d = direction;
+    return ray;
+}
+
+}  // namespace rtd

@@ -1,0 +1,91 @@
+// rt_kernels.h — kernel argument blocks and launch declarations shared by the
+// kernels (rt_kernels.hip) and the C-ABI (rt_api.hip).
+#pragma once
+
+#include "rt_device.h"
+
+namespace rtd
+{
+
+// Sink A: the probe keep-test grid (reference src/ProbeIndex.cpp) as an open-addressed
+// hash table in HBM, and the raw bounce store (reference src/BounceStore.cpp).
+struct ProbeView
+{
+    const int64_t* slotKey;      // [slots][3] cell coordinates
+    const uint32_t* slotStart;   // [slots] first probe of the cell in `points`
+    const uint32_t* slotCount;   // [slots] 0 = empty slot
+    const double* points;        // [probes][3], grouped by cell
+    uint64_t slotMask;           // slots - 1 (power of two)
+    uint64_t probeCount;
+    double invCellSize;
+    double keepRadius;
+    int64_t reach;               // ceil(keepRadius * invCellSize)
+};
+
+struct StoreView
+{
+    float* records;                  // [capacity][13]
+    unsigned long long* cursor;      // claimed slots, may exceed capacity
+    uint64_t capacity;
+};
+
+// Sink B density grid (reference src/DensityGrid.cpp): one 64-bit packed cell key per
+// slot claimed by compare-and-swap, power and count accumulated with atomics.
+struct DensityView
+{
+    unsigned long long* keys;  // [slots], kEmptyKey when free
+    float* power;              // [slots][3]
+    unsigned long long* count; // [slots]
+    uint64_t slotMask;
+    double invCellSize;
+    int32_t enabled;
+};
+constexpr unsigned long long kEmptyKey = ~0ull;
+constexpr int32_t kSinkNone = 0, kSinkProbe = 1, kSinkSplat = 2;  // rt_sink_mode of include/rt_amd.h
+
+struct DeviceCounters
+{
+    unsigned long long photons, casts, bounces, deposits, kept, culled;
+    unsigned long long splatTotal, splatRadiusClamped, splatLuminanceClamped;
+    unsigned long long densityCells, densityDeposits, densityOverflow;
+    double power[3];
+};
+
+struct RecordView
+{
+    uint64_t recordPhotons;
+    int32_t maxBounces;
+    double* emitted;      // [M][6]
+    int32_t* castsValid;  // [M][2]
+    double* f64;          // [M][B][10]
+    int32_t* i32;         // [M][B][8]
+    float* power;         // [M][B][3]
+};
+
+struct TraceArgs
+{
+    SceneView scene;
+    ProbeView probes;
+    StoreView store;
+    DensityView density;
+    RecordView records;
+    DeviceCounters* counters;
+    unsigned long long* workCounter;
+    uint64_t firstPhoton;
+    uint64_t photonCount;  // per light
+    uint64_t totalWork;    // lights * photonCount
+    double minSplatRadius;
+    int32_t sinkMode;
+};
+
+void launchTrace(const TraceArgs& args, int blocks, int threads, hipStream_t stream);
+void launchCastRays(const SceneView& scene, int64_t n, const double* rays, double selfHit, double* outF64,
+                    int32_t* outI32, hipStream_t stream);
+void launchEmit(const SceneView& scene, int32_t light, int64_t n, const double* draws5, uint64_t totalPhotons,
+                double* rays, float* colors, hipStream_t stream);
+void launchIntersect(int kind, int64_t n, const double* in, void* out, hipStream_t stream);
+void launchBsdfSample(int64_t n, const double* in14, double* out10, hipStream_t stream);
+void launchBsdfEvaluate(int64_t n, const double* in14, double* out4, hipStream_t stream);
+int traceBlocksPerCu();
+
+}  // namespace rtd

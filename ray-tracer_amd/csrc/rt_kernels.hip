@@ -1,0 +1,750 @@
+// rt_kernels.hip — the photon pass and the function-level kernels (gfx950).
+//
+// traceKernel is a persistent-thread tracer: the grid is sized to fill the chip
+// once, every wave pulls chunks of photon ids from one global counter, and every
+// LANE refills itself with a fresh photon as soon as its own photon terminates, so
+// all 64 lanes of a wave execute the same stage — one bounce (cast, deposit,
+// terminate-or-scatter) — on every trip round the loop whatever the individual
+// path lengths are.  It replaces Worker::exec / processLights / processPhotons
+// (reference src/Worker.cpp:116-174,429-680); the WorkQueue/LightQueue machinery
+// that bounded in-flight photons on the CPU (reference src/WorkQueue.cpp,
+// src/LightQueue.cpp) reduces to that counter, because photons are generated in
+// registers and never stored.
+
+#include "rt_kernels.h"
+
+namespace rtd
+{
+
+namespace
+{
+
+constexpr int kTraceThreads = 256;
+constexpr unsigned long long kChunk = 1024;  // photon ids a wave claims per atomic
+constexpr double kSelfHitThreshold = 1e-4;   // reference src/Worker.cpp:36
+
+RT_DEV unsigned lanesBelow(unsigned long long mask)
+{
+    return __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(mask >> 32),
+                                     __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(mask), 0u));
+}
+
+RT_DEV unsigned long long waveSum(unsigned long long v)
+{
+#pragma unroll
+    for (int offset = 32; offset > 0; offset >>= 1)
+    {
+        v += __shfl_down(v, offset, 64);
+    }
+    return v;
+}
+
+RT_DEV double waveSumD(double v)
+{
+#pragma unroll
+    for (int offset = 32; offset > 0; offset >>= 1)
+    {
+        v += __shfl_down(v, offset, 64);
+    }
+    return v;
+}
+
+// ProbeIndex::anyWithin, reference src/ProbeIndex.cpp:27-68.  The result is a pure
+// "exists", so the scan order is free; the squared-distance test is the reference's
+// expression.
+RT_DEV bool anyProbeWithin(const ProbeView& pv, const Vec& p)
+{
+    const double r = pv.keepRadius;
+    if (r <= 0.0 || pv.probeCount == 0)
+    {
+        return false;
+    }
+    const double r2 = r * r;
+    const int64_t cx = static_cast<int64_t>(__builtin_floor(p.x * pv.invCellSize));
+    const int64_t cy = static_cast<int64_t>(__builtin_floor(p.y * pv.invCellSize));
+    const int64_t cz = static_cast<int64_t>(__builtin_floor(p.z * pv.invCellSize));
+    const int64_t reach = pv.reach;
+    for (int64_t dz = -reach; dz <= reach; ++dz)
+    {
+        for (int64_t dy = -reach; dy <= reach; ++dy)
+        {
+            for (int64_t dx = -reach; dx <= reach; ++dx)
+            {
+                const int64_t kx = cx + dx, ky = cy + dy, kz = cz + dz;
+                uint64_t h = static_cast<uint64_t>(kx) * 73856093ull;
+                h ^= static_cast<uint64_t>(ky) * 19349663ull;
+                h ^= static_cast<uint64_t>(kz) * 83492791ull;
+                uint64_t slot = (h * 0x9E3779B97F4A7C15ull) >> 20 & pv.slotMask;
+                while (true)
+                {
+                    const uint32_t count = pv.slotCount[slot];
+                    if (count == 0)
+                    {
+                        break;
+                    }
+                    const int64_t* key = pv.slotKey + 3 * slot;
+                    if (key[0] == kx && key[1] == ky && key[2] == kz)
+                    {
+                        const double* pt = pv.points + 3ull * pv.slotStart[slot];
+                        for (uint32_t i = 0; i < count; ++i)
+                        {
+                            const double ddx = pt[3 * i] - p.x, ddy = pt[3 * i + 1] - p.y, ddz = pt[3 * i + 2] - p.z;
+                            if (ddx * ddx + ddy * ddy + ddz * ddz <= r2)
+                            {
+                                return true;
+                            }
+                        }
+                        break;
+                    }
+                    slot = (slot + 1) & pv.slotMask;
+                }
+            }
+        }
+    }
+    return false;
+}
+
+// BounceStore::append, reference src/BounceStore.cpp:11-20, with the cursor claimed
+// once per wave: the lanes that append in this step count themselves with a ballot,
+// one lane adds the total, each lane takes base + its rank.
+RT_DEV void storeAppend(const StoreView& sv, bool keep, const Vec& position, const Vec& incoming, const Vec& normal,
+                        float time, const Color& power)
+{
+    const unsigned long long mask = __ballot(keep);
+    if (mask == 0)
+    {
+        return;
+    }
+    const int leader = __builtin_ctzll(mask);
+    unsigned long long base = 0;
+    if (static_cast<int>(threadIdx.x & 63) == leader)
+    {
+        base = atomicAdd(sv.cursor, static_cast<unsigned long long>(__builtin_popcountll(mask)));
+    }
+    base = __shfl(base, leader, 64);
+    if (keep)
+    {
+        const unsigned long long slot = base + lanesBelow(mask);
+        if (slot < sv.capacity)
+        {
+            float* r = sv.records + 13ull * slot;
+            r[0] = static_cast<float>(position.x);
+            r[1] = static_cast<float>(position.y);
+            r[2] = static_cast<float>(position.z);
+            r[3] = static_cast<float>(incoming.x);
+            r[4] = static_cast<float>(incoming.y);
+            r[5] = static_cast<float>(incoming.z);
+            r[6] = static_cast<float>(normal.x);
+            r[7] = static_cast<float>(normal.y);
+            r[8] = static_cast<float>(normal.z);
+            r[9] = time;
+            r[10] = power.r;
+            r[11] = power.g;
+            r[12] = power.b;
+        }
+    }
+}
+
+// DensityGrid::add, reference src/DensityGrid.cpp:25-34.
+RT_DEV void densityAdd(const DensityView& dv, const Vec& p, const Color& power, unsigned long long& newCells,
+                       unsigned long long& overflow)
+{
+    const int64_t cx = static_cast<int64_t>(__builtin_floor(p.x * dv.invCellSize));
+    const int64_t cy = static_cast<int64_t>(__builtin_floor(p.y * dv.invCellSize));
+    const int64_t cz = static_cast<int64_t>(__builtin_floor(p.z * dv.invCellSize));
+    const int64_t lim = 1 << 20;
+    if (cx < -lim || cx >= lim || cy < -lim || cy >= lim || cz < -lim || cz >= lim)
+    {
+        overflow += 1;
+        return;
+    }
+    const unsigned long long key = (static_cast<unsigned long long>(cx + lim) << 42) |
+                                   (static_cast<unsigned long long>(cy + lim) << 21) |
+                                   static_cast<unsigned long long>(cz + lim);
+    uint64_t h = static_cast<uint64_t>(cx) * 73856093ull;
+    h ^= static_cast<uint64_t>(cy) * 19349663ull;
+    h ^= static_cast<uint64_t>(cz) * 83492791ull;
+    uint64_t slot = (h * 0x9E3779B97F4A7C15ull) >> 20 & dv.slotMask;
+    for (uint64_t tries = 0; tries <= dv.slotMask; ++tries)
+    {
+        const unsigned long long seen = atomicCAS(dv.keys + slot, kEmptyKey, key);
+        if (seen == kEmptyKey || seen == key)
+        {
+            if (seen == kEmptyKey)
+            {
+                newCells += 1;
+            }
+            atomicAdd(dv.power + 3 * slot + 0, power.r);
+            atomicAdd(dv.power + 3 * slot + 1, power.g);
+            atomicAdd(dv.power + 3 * slot + 2, power.b);
+            atomicAdd(dv.count + slot, 1ull);
+            return;
+        }
+        slot = (slot + 1) & dv.slotMask;
+    }
+    overflow += 1;
+}
+
+struct LocalCounters
+{
+    unsigned long long photons = 0, casts = 0, bounces = 0, deposits = 0, kept = 0, culled = 0;
+    unsigned long long splatTotal = 0, splatRadiusClamped = 0, splatLuminanceClamped = 0;
+    unsigned long long densityCells = 0, densityDeposits = 0, densityOverflow = 0;
+    double power[3] = {0.0, 0.0, 0.0};
+};
+
+// Worker::splatToCamera, reference src/Worker.cpp:221-427, with
+// Camera::coordForPointSubPixel (src/Camera.cpp:239-310), Utility::flooredSplatRadius
+// (src/Utility.cpp:43-50) and Buffer::addColor (src/Buffer.cpp:22-37).
+RT_DEV void splatToCamera(const TraceArgs& a, const Vec& incoming, const Color& photonColor, int bounces, int lightId,
+                          float time, const Hit& hit, const Material& material, LocalCounters& lc)
+{
+    const SceneView& s = a.scene;
+    if (materialIsDelta(material.type) || static_cast<double>(s.photonsPerLight) <= 0.0)
+    {
+        return;
+    }
+    const Vec wi = neg(incoming);
+    for (int32_t c = 0; c < s.cameraCount; ++c)
+    {
+        const Camera& cam = s.cameras[c];
+        if (cam.bounceFilter >= 0 && bounces != cam.bounceFilter) continue;
+        if (cam.lightFilter >= 0 && lightId != cam.lightFilter) continue;
+        if (cam.width <= 0 || cam.height <= 0) continue;
+        const Vec eye = mk(cam.pos[0], cam.pos[1], cam.pos[2]);
+        const Vec toPoint = hit.position - eye;
+        const double depth = dot(toPoint, mk(cam.forward[0], cam.forward[1], cam.forward[2]));
+        if (depth <= 0.0) continue;
+        if (cam.halfHeight <= 0.0) continue;
+        const double dx = dot(toPoint, mk(cam.right[0], cam.right[1], cam.right[2]));
+        const double dy = dot(toPoint, mk(cam.up[0], cam.up[1], cam.up[2]));
+        const double sx = (dx / depth) / (cam.aspect * cam.halfHeight);
+        const double sy = (dy / depth) / cam.halfHeight;
+        if (sx < -1.0 || sx > 1.0 || sy < -1.0 || sy > 1.0) continue;
+        const double subX = ((sx + 1.0) / 2.0) * static_cast<double>(cam.width);
+        const double subY = ((sy + 1.0) / 2.0) * static_cast<double>(cam.height);
+        const uint64_t w = static_cast<uint64_t>(cam.width), h = static_cast<uint64_t>(cam.height);
+        uint64_t px = static_cast<uint64_t>(dmax(0.0, __builtin_floor(subX)));
+        uint64_t py = static_cast<uint64_t>(dmax(0.0, __builtin_floor(subY)));
+        px = px < w - 1 ? px : w - 1;
+        py = py < h - 1 ? py : h - 1;
+
+        if (!(time >= cam.windowStart && time < cam.windowEnd)) continue;
+
+        const Vec toCamera = eye - hit.position;
+        const double cameraDistance = magnitude(toCamera);
+        if (cameraDistance < kSelfHitThreshold) continue;
+        const Vec toCameraDir = toCamera / cameraDistance;
+        const double cosCamera = dot(toCameraDir, hit.normal);
+        if (cosCamera <= 0.0) continue;
+
+        Ray shadow;
+        shadow.o = hit.position;
+        shadow.d = toCameraDir;
+        Hit occluder;
+        if (castScene(s, shadow, kSelfHitThreshold, false, &occluder) && occluder.distance < cameraDistance)
+        {
+            continue;
+        }
+
+        const double rawRadius = cameraDistance * cam.tanPixelHalfAngle;
+        const double r = (a.minSplatRadius > 0.0 && rawRadius < a.minSplatRadius) ? a.minSplatRadius : rawRadius;
+        lc.splatTotal += 1;
+        if (r > rawRadius) lc.splatRadiusClamped += 1;
+        if (r <= 0.0) continue;
+
+        const Color brdf = evaluateMaterial(material, wi, toCameraDir, hit.normal);
+        const double area = kPi * r * r;
+        const float scale = static_cast<float>(cosCamera / area);
+        const Color contribution = brdf * photonColor * scale;
+        if (brightness(contribution) <= 0.0f) continue;
+
+        Color clamped = contribution;
+        if (s.splatLuminanceClamp > 0.0)
+        {
+            const double b = static_cast<double>(brightness(contribution));
+            if (b > s.splatLuminanceClamp)
+            {
+                clamped = contribution * static_cast<float>(s.splatLuminanceClamp / b);
+                lc.splatLuminanceClamped += 1;
+            }
+        }
+        const uint64_t index = ((py * w) + px) * 3;
+        if (index + 2 >= w * h * 3) continue;
+        atomicAdd(cam.buffer + index + 0, clamped.r);
+        atomicAdd(cam.buffer + index + 1, clamped.g);
+        atomicAdd(cam.buffer + index + 2, clamped.b);
+    }
+}
+
+__global__ __launch_bounds__(kTraceThreads) void traceKernel(const TraceArgs a)
+{
+    const SceneView& s = a.scene;
+    const int lane = threadIdx.x & 63;
+
+    // wave-uniform claim of photon ids
+    unsigned long long chunkNext = 0, chunkEnd = 0;
+
+    bool alive = false, finished = false;
+    Ray ray;
+    ray.o = mk(0, 0, 0);
+    ray.d = mk(0, 0, 1);
+    Color color{0.0f, 0.0f, 0.0f};
+    int bounces = 0, lightId = 0;
+    float time = 0.0f;
+    unsigned long long photonIndex = 0;
+    long long recordSlot = -1;
+    int casts = 0, valid = 0;
+    LocalCounters lc;
+    Rng rng;
+    rng.tape = nullptr;
+    rng.next = 0;
+    rng.seed = s.seed;
+
+    while (true)
+    {
+        // ---- refill idle lanes (Worker::processLights + Light::emit) ----
+        const bool need = !alive && !finished;
+        const unsigned long long needMask = __ballot(need);
+        if (needMask != 0)
+        {
+            const unsigned long long n = static_cast<unsigned long long>(__builtin_popcountll(needMask));
+            const unsigned long long rank = lanesBelow(needMask);
+            const unsigned long long avail = chunkEnd - chunkNext;
+            unsigned long long id;
+            if (n > avail)
+            {
+                unsigned long long fresh = 0;
+                if (lane == __builtin_ctzll(needMask))
+                {
+                    fresh = atomicAdd(a.workCounter, kChunk);
+                }
+                fresh = __shfl(fresh, __builtin_ctzll(needMask), 64);
+                id = rank < avail ? chunkNext + rank : fresh + (rank - avail);
+                chunkNext = fresh + (n - avail);
+                chunkEnd = fresh + kChunk;
+            }
+            else
+            {
+                id = chunkNext + rank;
+                chunkNext += n;
+            }
+            if (need)
+            {
+                if (id < a.totalWork)
+                {
+                    lightId = static_cast<int>(id / a.photonCount);
+                    photonIndex = a.firstPhoton + id % a.photonCount;
+                    const Light& light = s.lights[lightId];
+                    rng.begin(static_cast<uint32_t>(lightId), photonIndex, RT_STAGE_EMIT);
+                    ray = emitRay(light, rng);
+                    // LightQueue::registerLight bakes Phi / N (reference src/LightQueue.cpp:16)
+                    const double photonFlux =
+                        s.photonsPerLight > 0 ? light.flux / static_cast<double>(s.photonsPerLight) : 0.0;
+                    color = Color{light.color[0], light.color[1], light.color[2]} * static_cast<float>(photonFlux);
+                    bounces = 0;
+                    time = 0.0f;
+                    // time stamp, reference src/Worker.cpp:486-498
+                    if (s.hasCamera && !__builtin_isinf(s.windowStart) && !__builtin_isnan(s.windowStart))
+                    {
+                        const bool finiteSpan = !__builtin_isinf(s.windowEnd) && !__builtin_isnan(s.windowEnd) &&
+                                                s.windowEnd > s.windowStart;
+                        if (finiteSpan)
+                        {
+                            const float span = s.windowEnd - s.windowStart;
+                            rng.begin(static_cast<uint32_t>(lightId), photonIndex, RT_STAGE_TIME);
+                            time = s.windowStart + static_cast<float>(rng.value(static_cast<double>(span)));
+                        }
+                        else
+                        {
+                            time = s.windowStart;
+                        }
+                    }
+                    recordSlot = id < a.records.recordPhotons ? static_cast<long long>(id) : -1;
+                    if (recordSlot >= 0)
+                    {
+                        double* e = a.records.emitted + 6 * recordSlot;
+                        e[0] = ray.o.x; e[1] = ray.o.y; e[2] = ray.o.z;
+                        e[3] = ray.d.x; e[4] = ray.d.y; e[5] = ray.d.z;
+                    }
+                    casts = 0;
+                    valid = 0;
+                    alive = true;
+                }
+                else
+                {
+                    finished = true;
+                }
+            }
+        }
+        if (__ballot(alive) == 0)
+        {
+            break;
+        }
+
+        // ---- one bounce (Worker::processPhotons loop body, src/Worker.cpp:530-673) ----
+        if (alive)
+        {
+            bool done = false;
+            if (static_cast<double>(brightness(color)) < kEps)
+            {
+                done = true;
+            }
+            Hit hit;
+            if (!done)
+            {
+                casts += 1;
+                if (!castScene(s, ray, kSelfHitThreshold, true, &hit))
+                {
+                    done = true;  // escaped the scene
+                }
+            }
+            if (!done)
+            {
+                const Material& material = s.materials[hit.material];
+                const bool delta = materialIsDelta(material.type);
+                if (recordSlot >= 0 && valid < a.records.maxBounces)
+                {
+                    const long long slot = recordSlot * a.records.maxBounces + valid;
+                    double* f = a.records.f64 + 10 * slot;
+                    f[0] = hit.position.x; f[1] = hit.position.y; f[2] = hit.position.z;
+                    f[3] = hit.normal.x; f[4] = hit.normal.y; f[5] = hit.normal.z;
+                    f[6] = hit.distance;
+                    f[7] = ray.d.x; f[8] = ray.d.y; f[9] = ray.d.z;
+                    int32_t* r = a.records.i32 + 8 * slot;
+                    r[0] = static_cast<int32_t>(photonIndex); r[1] = bounces; r[2] = hit.volume; r[3] = hit.triangle;
+                    r[4] = hit.material; r[5] = 0; r[6] = delta ? 1 : 0; r[7] = lightId;
+                    float* p = a.records.power + 3 * slot;
+                    p[0] = color.r; p[1] = color.g; p[2] = color.b;
+                }
+                valid += 1;
+                if (!delta)
+                {
+                    lc.deposits += 1;
+                    lc.power[0] += color.r;
+                    lc.power[1] += color.g;
+                    lc.power[2] += color.b;
+                }
+                if (a.sinkMode == kSinkProbe)
+                {
+                    bool keep = false;
+                    if (!delta)
+                    {
+                        keep = anyProbeWithin(a.probes, hit.position);
+                        if (keep) lc.kept += 1;
+                        else lc.culled += 1;
+                    }
+                    storeAppend(a.store, keep, hit.position, ray.d, hit.normal, time, color);
+                }
+                else if (a.sinkMode == kSinkSplat)
+                {
+                    if (a.density.enabled && !delta)
+                    {
+                        lc.densityDeposits += 1;
+                        densityAdd(a.density, hit.position, color, lc.densityCells, lc.densityOverflow);
+                    }
+                    splatToCamera(a, ray.d, color, bounces, lightId, time, hit, material, lc);
+                }
+
+                // terminate: absolute decay floor or bounce cap (src/Worker.cpp:640-644,
+                // include/Photon.h:55-72)
+                const float mag = fmaxf(fmaxf(color.r, color.g), color.b);
+                const bool decayAlive = static_cast<double>(mag) > s.terminationThreshold;
+                if (!decayAlive || bounces >= s.bounceThreshold)
+                {
+                    done = true;
+                }
+                else
+                {
+                    // Material::generateDaughters with one daughter (src/Material.cpp:87-145)
+                    rng.begin(static_cast<uint32_t>(lightId), photonIndex,
+                              RT_STAGE_SCATTER + static_cast<uint32_t>(bounces));
+                    const BSDFSample smp = sampleMaterial(material, ray.d, hit.normal, rng);
+                    bounces += 1;
+                    ray.o = hit.position;
+                    if (!smp.valid)
+                    {
+                        ray.d = hit.normal;
+                        color = Color{0.0f, 0.0f, 0.0f};
+                    }
+                    else
+                    {
+                        ray.d = smp.direction;
+                        color = color * smp.weight;
+                    }
+                }
+            }
+            else
+            {
+                // lanes that ended before the sink stage still take part in the wave-level
+                // store append below with keep = false
+            }
+            if (done)
+            {
+                if (recordSlot >= 0)
+                {
+                    a.records.castsValid[2 * recordSlot + 0] = casts;
+                    a.records.castsValid[2 * recordSlot + 1] = valid;
+                }
+                lc.photons += 1;
+                lc.casts += static_cast<unsigned long long>(casts);
+                lc.bounces += static_cast<unsigned long long>(valid);
+                alive = false;
+            }
+        }
+    }
+
+    // ---- flush counters: one atomic per wave per counter ----
+    unsigned long long sums[12] = {lc.photons, lc.casts, lc.bounces, lc.deposits, lc.kept, lc.culled,
+                                   lc.splatTotal, lc.splatRadiusClamped, lc.splatLuminanceClamped,
+                                   lc.densityCells, lc.densityDeposits, lc.densityOverflow};
+    unsigned long long* dst = &a.counters->photons;
+#pragma unroll
+    for (int k = 0; k < 12; ++k)
+    {
+        const unsigned long long total = waveSum(sums[k]);
+        if (lane == 0 && total != 0)
+        {
+            atomicAdd(dst + k, total);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+    {
+        const double total = waveSumD(lc.power[k]);
+        if (lane == 0 && total != 0.0)
+        {
+            atomicAdd(&a.counters->power[k], total);
+        }
+    }
+}
+
+// ---------------------------------------------------------------- function-level kernels
+
+__global__ void castRaysKernel(const SceneView s, int64_t n, const double* rays, double selfHit, double* outF64,
+                               int32_t* outI32)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Ray ray;
+    ray.o = mk(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]);
+    ray.d = mk(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]);
+    Hit hit;
+    const bool found = castScene(s, ray, selfHit, true, &hit);
+    double* f = outF64 + 7 * i;
+    int32_t* o = outI32 + 4 * i;
+    if (found)
+    {
+        f[0] = hit.position.x; f[1] = hit.position.y; f[2] = hit.position.z;
+        f[3] = hit.normal.x; f[4] = hit.normal.y; f[5] = hit.normal.z;
+        f[6] = hit.distance;
+        o[0] = 1; o[1] = hit.volume; o[2] = hit.triangle; o[3] = hit.material;
+    }
+    else
+    {
+        for (int k = 0; k < 7; ++k) f[k] = 0.0;
+        o[0] = 0; o[1] = -1; o[2] = -1; o[3] = -1;
+    }
+}
+
+__global__ void emitKernel(const SceneView s, int32_t lightIndex, int64_t n, const double* draws5,
+                           uint64_t totalPhotons, double* rays, float* colors)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Light& light = s.lights[lightIndex];
+    Rng rng;
+    rng.tape = draws5 + 5 * i;
+    rng.next = 0;
+    rng.seed = 0;
+    const Ray ray = emitRay(light, rng);
+    const double photonFlux = light.flux / static_cast<double>(totalPhotons);
+    const Color color = Color{light.color[0], light.color[1], light.color[2]} * static_cast<float>(photonFlux);
+    double* o = rays + 6 * i;
+    o[0] = ray.o.x; o[1] = ray.o.y; o[2] = ray.o.z;
+    o[3] = ray.d.x; o[4] = ray.d.y; o[5] = ray.d.z;
+    colors[3 * i] = color.r; colors[3 * i + 1] = color.g; colors[3 * i + 2] = color.b;
+}
+
+RT_DEV void writeHit(double* out, bool found, const Vec& position, const Vec& normal, double distance)
+{
+    out[0] = found ? 1.0 : 0.0;
+    out[1] = found ? position.x : 0.0; out[2] = found ? position.y : 0.0; out[3] = found ? position.z : 0.0;
+    out[4] = found ? normal.x : 0.0; out[5] = found ? normal.y : 0.0; out[6] = found ? normal.z : 0.0;
+    out[7] = found ? distance : 0.0;
+}
+
+__global__ void intersectKernel(int kind, int64_t n, const double* in, void* outRaw)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Vec position = mk(0, 0, 0), normal = mk(0, 0, 0);
+    double distance = 0.0;
+    if (kind == 0)  // triangle: ray(6) a b c aN bN cN
+    {
+        const double* r = in + 24 * i;
+        Ray ray;
+        ray.o = mk(r[0], r[1], r[2]);
+        ray.d = mk(r[3], r[4], r[5]);
+        const RayPrep prep = prepareRay(ray);
+        double bary[3];
+        const bool found = rayIntersectsTriangle(ray, prep, r + 6, bary, &position, &distance);
+        if (found) normal = triangleNormal(r + 15, bary);
+        writeHit(static_cast<double*>(outRaw) + 8 * i, found, position, normal, distance);
+    }
+    else if (kind == 1)  // bounds: ray(6) corner corner (each axis sorted, reference src/Bounds.cpp:5-9)
+    {
+        const double* r = in + 12 * i;
+        Ray ray;
+        ray.o = mk(r[0], r[1], r[2]);
+        ray.d = mk(r[3], r[4], r[5]);
+        double lo[3], hi[3], entry;
+        for (int k = 0; k < 3; ++k)
+        {
+            lo[k] = dmin(r[6 + k], r[9 + k]);
+            hi[k] = dmax(r[6 + k], r[9 + k]);
+        }
+        const bool direct = rayIntersectsBounds(ray, lo, hi, &entry);
+        const RayPrep prep = prepareRay(ray);
+        const bool hoisted = slabTest(ray, prep, lo, hi, &entry);
+        // both forms must agree; report 2 if they ever do not
+        static_cast<int32_t*>(outRaw)[i] = direct == hoisted ? (direct ? 1 : 0) : 2;
+    }
+    else if (kind == 2)  // sphere: ray(6) center radius
+    {
+        const double* r = in + 10 * i;
+        Ray ray;
+        ray.o = mk(r[0], r[1], r[2]);
+        ray.d = mk(r[3], r[4], r[5]);
+        const bool found = rayIntersectsSphere(ray, mk(r[6], r[7], r[8]), r[9], &position, &normal, &distance);
+        writeHit(static_cast<double*>(outRaw) + 8 * i, found, position, normal, distance);
+    }
+    else if (kind == 3)  // quad: ray(6) origin edgeU edgeV
+    {
+        const double* r = in + 15 * i;
+        Ray ray;
+        ray.o = mk(r[0], r[1], r[2]);
+        ray.d = mk(r[3], r[4], r[5]);
+        double q[18];
+        for (int k = 0; k < 9; ++k) q[k] = r[6 + k];
+        quadUpdate(q);
+        Vec uv = mk(0, 0, 0);
+        const bool found = rayIntersectsQuad(ray, q, &position, &normal, &distance, &uv);
+        double* o = static_cast<double*>(outRaw) + 20 * i;
+        writeHit(o, found, position, normal, distance);
+        o[8] = found ? uv.x : 0.0; o[9] = found ? uv.y : 0.0; o[10] = found ? uv.z : 0.0;
+        for (int k = 0; k < 9; ++k) o[11 + k] = q[9 + k];
+    }
+    else  // plane: ray(6) normal dot
+    {
+        const double* r = in + 10 * i;
+        Ray ray;
+        ray.o = mk(r[0], r[1], r[2]);
+        ray.d = mk(r[3], r[4], r[5]);
+        const bool found = rayIntersectsPlane(ray, mk(r[6], r[7], r[8]), r[9], &position, &normal, &distance);
+        writeHit(static_cast<double*>(outRaw) + 8 * i, found, position, normal, distance);
+    }
+}
+
+RT_DEV Material materialFromRow(const double* r)
+{
+    Material m;
+    m.type = static_cast<int32_t>(r[0]);
+    m.pad = 0;
+    m.color[0] = static_cast<float>(r[1]);
+    m.color[1] = static_cast<float>(r[2]);
+    m.color[2] = static_cast<float>(r[3]);
+    m.pad2 = 0.0f;
+    m.alpha = r[4];
+    m.ior = 1.5;
+    return m;
+}
+
+__global__ void bsdfSampleKernel(int64_t n, const double* in, double* out)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double* r = in + 14 * i;
+    Material m = materialFromRow(r);
+    m.ior = r[5];
+    Rng rng;
+    rng.tape = r + 12;
+    rng.next = 0;
+    rng.seed = 0;
+    const BSDFSample s = sampleMaterial(m, mk(r[6], r[7], r[8]), mk(r[9], r[10], r[11]), rng);
+    double* o = out + 10 * i;
+    o[0] = s.valid ? 1.0 : 0.0;
+    o[1] = s.direction.x; o[2] = s.direction.y; o[3] = s.direction.z;
+    o[4] = s.weight.r; o[5] = s.weight.g; o[6] = s.weight.b;
+    o[7] = s.pdf;
+    o[8] = s.isDelta ? 1.0 : 0.0;
+    o[9] = materialIsDelta(m.type) ? 1.0 : 0.0;
+}
+
+__global__ void bsdfEvaluateKernel(int64_t n, const double* in, double* out)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double* r = in + 14 * i;
+    const Material m = materialFromRow(r);
+    const Vec wi = mk(r[5], r[6], r[7]), wo = mk(r[8], r[9], r[10]), nn = mk(r[11], r[12], r[13]);
+    const Color f = evaluateMaterial(m, wi, wo, nn);
+    double* o = out + 4 * i;
+    o[0] = f.r; o[1] = f.g; o[2] = f.b;
+    o[3] = pdfMaterial(m, wi, wo, nn);
+}
+
+int gridFor(int64_t n) { return static_cast<int>((n + 255) / 256); }
+
+}  // namespace
+
+void launchTrace(const TraceArgs& args, int blocks, int threads, hipStream_t stream)
+{
+    (void)threads;
+    hipLaunchKernelGGL(traceKernel, dim3(blocks), dim3(kTraceThreads), 0, stream, args);
+}
+
+int traceBlocksPerCu()
+{
+    int blocks = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, traceKernel, kTraceThreads, 0) != hipSuccess || blocks < 1)
+    {
+        blocks = 2;
+    }
+    return blocks;
+}
+
+void launchCastRays(const SceneView& scene, int64_t n, const double* rays, double selfHit, double* outF64,
+                    int32_t* outI32, hipStream_t stream)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(castRaysKernel, dim3(gridFor(n)), dim3(256), 0, stream, scene, n, rays, selfHit, outF64, outI32);
+}
+
+void launchEmit(const SceneView& scene, int32_t light, int64_t n, const double* draws5, uint64_t totalPhotons,
+                double* rays, float* colors, hipStream_t stream)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(emitKernel, dim3(gridFor(n)), dim3(256), 0, stream, scene, light, n, draws5, totalPhotons, rays,
+                       colors);
+}
+
+void launchIntersect(int kind, int64_t n, const double* in, void* out, hipStream_t stream)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(intersectKernel, dim3(gridFor(n)), dim3(256), 0, stream, kind, n, in, out);
+}
+
+void launchBsdfSample(int64_t n, const double* in14, double* out10, hipStream_t stream)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(bsdfSampleKernel, dim3(gridFor(n)), dim3(256), 0, stream, n, in14, out10);
+}
+
+void launchBsdfEvaluate(int64_t n, const double* in14, double* out4, hipStream_t stream)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(bsdfEvaluateKernel, dim3(gridFor(n)), dim3(256), 0, stream, n, in14, out4);
+}
+
+}  // namespace rtd

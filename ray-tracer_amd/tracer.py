@@ -1,9 +1,230 @@
-"""ctypes wrapper of the tracer's C-ABI (include/rt_amd.h) — filled in with the HIP library."""
+"""ctypes wrapper of the tracer's C-ABI (include/rt_amd.h).
+
+Loads csrc/librt_amd.so and raises if it is missing — there is no CPU path to fall
+back to.  Arrays cross the boundary as numpy buffers (host pointers) or as raw
+device pointers taken from torch tensors (camera buffers).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+SINK_NONE, SINK_PROBE, SINK_SPLAT = 0, 1, 2
+RT_OK = 0
+
+COUNTER_FIELDS = (
+    "photons", "casts", "bounces", "deposits", "kept", "culled", "store_attempted", "store_size",
+    "store_dropped", "splat_total", "splat_radius_clamped", "splat_luminance_clamped", "density_cells",
+    "density_deposits",
+)
+
+
+class RtCounters(C.Structure):
+    _fields_ = [(name, C.c_uint64) for name in COUNTER_FIELDS] + [("deposited_power", C.c_double * 3)]
+
+
+class RtTraceParams(C.Structure):
+    _fields_ = [
+        ("sink_mode", C.c_int32), ("reserved", C.c_int32), ("first_photon", C.c_uint64),
+        ("photon_count", C.c_uint64), ("record_photons", C.c_uint64),
+    ]
+
+
+# every symbol include/rt_amd.h declares, with its ctypes signature
+_SIGNATURES = {
+    "rt_last_error": (C.c_char_p, []),
+    "rt_abi_struct_size": (C.c_uint64, [C.c_int32]),
+    "rt_device_count": (C.c_int32, []),
+    "rt_create": (C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]),
+    "rt_destroy": (None, [C.c_void_p]),
+    "rt_set_stream": (C.c_int32, [C.c_void_p, C.c_void_p]),
+    "rt_set_probes": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_double, C.c_double, C.c_uint64]),
+    "rt_set_splat": (C.c_int32, [C.c_void_p, C.c_double, C.c_double, C.c_uint64]),
+    "rt_bind_camera_buffer": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p]),
+    "rt_reset": (C.c_int32, [C.c_void_p]),
+    "rt_trace": (C.c_int32, [C.c_void_p, C.POINTER(RtTraceParams)]),
+    "rt_synchronize": (C.c_int32, [C.c_void_p]),
+    "rt_read_counters": (C.c_int32, [C.c_void_p, C.POINTER(RtCounters)]),
+    "rt_read_camera_buffer": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p]),
+    "rt_read_store": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "rt_read_density": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
+                                    C.POINTER(C.c_uint64)]),
+    "rt_read_records": (C.c_int32, [C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_void_p]),
+    "rt_cast_rays": (C.c_int32, [C.c_void_p, C.c_int64, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]),
+    "rt_emit": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
+    "rt_intersect_triangles": (C.c_int32, [C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]),
+    "rt_intersect_bounds": (C.c_int32, [C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]),
+    "rt_intersect_spheres": (C.c_int32, [C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]),
+    "rt_intersect_quads": (C.c_int32, [C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]),
+    "rt_intersect_planes": (C.c_int32, [C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]),
+    "rt_bsdf_sample": (C.c_int32, [C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]),
+    "rt_bsdf_evaluate": (C.c_int32, [C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]),
+}
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+TRACER_LIB_PATH = os.path.join(_HERE, "csrc", "librt_amd.so")
+_lib = None
+
+
+def declared_symbols():
+    return sorted(_SIGNATURES)
 
 
 def tracer_lib():
-    raise RuntimeError("librt_amd.so wrapper not available yet")
+    """The HIP tracer library; raises when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(TRACER_LIB_PATH):
+            raise RuntimeError(f"{TRACER_LIB_PATH} is not built; run __graft_entry__.build() "
+                               "(there is no CPU fallback for the photon pass)")
+        lib = C.CDLL(TRACER_LIB_PATH)
+        for name, (restype, argtypes) in _SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = lib
+    return _lib
+
+
+class TracerError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"rt_amd error {code}: {message}")
+        self.code = code
+
+
+def _check(code):
+    if code != RT_OK:
+        raise TracerError(code, tracer_lib().rt_last_error().decode())
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def rows(fn_name, inputs, out_cols, out_dtype=np.float64, device=0):
+    """Run a device function-level entry point over rows of `inputs`."""
+    a = np.ascontiguousarray(inputs, dtype=np.float64)
+    shape = (a.shape[0],) + ((out_cols,) if out_cols else ())
+    out = np.zeros(shape, dtype=out_dtype)
+    _check(getattr(tracer_lib(), fn_name)(device, a.shape[0], _ptr(a), _ptr(out)))
+    return out
 
 
 class Tracer:
-    pass
+    """One rt_tracer handle: a scene resident on one GPU."""
+
+    def __init__(self, scene, device=0):
+        self.scene = scene
+        self.device = device
+        handle = C.c_void_p()
+        _check(tracer_lib().rt_create(C.cast(scene.ptr, C.c_void_p), device, C.byref(handle)))
+        self._handle = handle
+        desc = scene.desc
+        self.cameras = [(desc.cameras[c].width, desc.cameras[c].height) for c in range(desc.camera_count)]
+        self.light_count = int(desc.light_count)
+        self.max_bounces = int(desc.settings.bounce_threshold) + 1
+
+    def close(self):
+        if getattr(self, "_handle", None):
+            tracer_lib().rt_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- set-up -------------------------------------------------------------
+    def set_stream(self, hip_stream):
+        _check(tracer_lib().rt_set_stream(self._handle, C.c_void_p(hip_stream)))
+
+    def set_probes(self, probes, cell_size, keep_radius, store_capacity):
+        probes = np.ascontiguousarray(probes, dtype=np.float64).reshape(-1, 3)
+        _check(tracer_lib().rt_set_probes(self._handle, _ptr(probes), probes.shape[0], cell_size, keep_radius,
+                                          store_capacity))
+
+    def set_splat(self, min_splat_radius, density_cell_size=0.0, density_capacity=1 << 20):
+        _check(tracer_lib().rt_set_splat(self._handle, min_splat_radius, density_cell_size, density_capacity))
+
+    def bind_camera_buffer(self, camera, device_pointer):
+        _check(tracer_lib().rt_bind_camera_buffer(self._handle, camera, C.c_void_p(device_pointer)))
+
+    def reset(self):
+        _check(tracer_lib().rt_reset(self._handle))
+
+    # -- the photon pass ----------------------------------------------------
+    def trace(self, sink_mode=SINK_NONE, first_photon=0, photon_count=0, record_photons=0):
+        params = RtTraceParams(sink_mode, 0, first_photon, photon_count, record_photons)
+        _check(tracer_lib().rt_trace(self._handle, C.byref(params)))
+
+    def synchronize(self):
+        _check(tracer_lib().rt_synchronize(self._handle))
+
+    # -- read-back ----------------------------------------------------------
+    def counters(self):
+        c = RtCounters()
+        _check(tracer_lib().rt_read_counters(self._handle, C.byref(c)))
+        out = {name: int(getattr(c, name)) for name in COUNTER_FIELDS}
+        out["deposited_power"] = np.array(list(c.deposited_power))
+        return out
+
+    def camera_buffer(self, camera):
+        w, h = self.cameras[camera]
+        out = np.zeros((h, w, 3), dtype=np.float32)
+        _check(tracer_lib().rt_read_camera_buffer(self._handle, camera, _ptr(out)))
+        return out
+
+    def store(self, max_records=None):
+        n = C.c_uint64()
+        _check(tracer_lib().rt_read_store(self._handle, None, 0, C.byref(n)))
+        count = int(n.value) if max_records is None else min(int(n.value), max_records)
+        out = np.zeros((count, 13), dtype=np.float32)
+        if count:
+            _check(tracer_lib().rt_read_store(self._handle, _ptr(out), count, C.byref(n)))
+        return out
+
+    def density(self):
+        n = C.c_uint64()
+        _check(tracer_lib().rt_read_density(self._handle, None, None, None, 0, C.byref(n)))
+        count = int(n.value)
+        keys = np.zeros((count, 3), dtype=np.int64)
+        power = np.zeros((count, 3), dtype=np.float32)
+        counts = np.zeros((count,), dtype=np.uint64)
+        if count:
+            _check(tracer_lib().rt_read_density(self._handle, _ptr(keys), _ptr(power), _ptr(counts), count,
+                                                C.byref(n)))
+        return keys, power, counts
+
+    def records(self):
+        n = C.c_uint64()
+        _check(tracer_lib().rt_read_records(self._handle, C.byref(n), None, None, None, None, None))
+        m, b = int(n.value), self.max_bounces
+        out = {
+            "emitted": np.zeros((m, 6)), "casts_valid": np.zeros((m, 2), dtype=np.int32),
+            "bounce_f64": np.zeros((m, b, 10)), "bounce_i32": np.zeros((m, b, 8), dtype=np.int32),
+            "bounce_power": np.zeros((m, b, 3), dtype=np.float32),
+        }
+        if m:
+            _check(tracer_lib().rt_read_records(self._handle, C.byref(n), _ptr(out["emitted"]),
+                                                _ptr(out["casts_valid"]), _ptr(out["bounce_f64"]),
+                                                _ptr(out["bounce_i32"]), _ptr(out["bounce_power"])))
+        return out
+
+    # -- function-level -----------------------------------------------------
+    def cast_rays(self, rays, self_hit=1e-4):
+        rays = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 6)
+        n = rays.shape[0]
+        f = np.zeros((n, 7))
+        i = np.zeros((n, 4), dtype=np.int32)
+        _check(tracer_lib().rt_cast_rays(self._handle, n, _ptr(rays), self_hit, _ptr(f), _ptr(i)))
+        return f, i
+
+    def emit(self, light, draws5, total_photons):
+        draws5 = np.ascontiguousarray(draws5, dtype=np.float64).reshape(-1, 5)
+        n = draws5.shape[0]
+        rays = np.zeros((n, 6))
+        colors = np.zeros((n, 3), dtype=np.float32)
+        _check(tracer_lib().rt_emit(self._handle, light, n, _ptr(draws5), total_photons, _ptr(rays), _ptr(colors)))
+        return rays, colors

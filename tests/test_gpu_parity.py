@@ -1,0 +1,242 @@
+"""HIP path vs the reference's golden vectors and vs the CPU oracle (MI355X only).
+
+Everything here goes through the C-ABI of librt_amd.so.  Bar: bit-exact for hits,
+ids, bounce counts, photon power and store records; camera buffers (float atomics,
+order-dependent) to 1e-5 relative.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from conftest import REPO, assert_bits_equal
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def tracer_mod():
+    from importlib import import_module
+    return import_module("ray-tracer_amd.tracer")
+
+
+UNIT = [
+    ("tri", "rt_intersect_triangles", 8, np.float64),
+    ("bounds", "rt_intersect_bounds", 0, np.int32),
+    ("sphere", "rt_intersect_spheres", 8, np.float64),
+    ("quad", "rt_intersect_quads", 20, np.float64),
+    ("plane", "rt_intersect_planes", 8, np.float64),
+    ("eval", "rt_bsdf_evaluate", 4, np.float64),
+]
+
+
+@pytest.mark.parametrize("name,fn,cols,dtype", UNIT)
+def test_device_intersectors_match_reference_bits(tracer_mod, golden, name, fn, cols, dtype):
+    g = golden("unit")
+    got = tracer_mod.rows(fn, g[f"{name}_in"], cols, dtype)
+    assert_bits_equal(got, g[f"{name}_out"].astype(dtype), name)
+
+
+def test_device_bsdf_sample(tracer_mod, golden):
+    """Mirror and dielectric use no transcendental: bit-exact vs the reference.  Lambert and
+    microfacet go through the shared sin/cos: bit-exact vs the oracle in portable mode, and
+    within a few ulp of the reference."""
+    g = golden("unit")
+    got = tracer_mod.rows("rt_bsdf_sample", g["bsdf_in"], 10)
+    ref = g["bsdf_out"]
+    delta = np.isin(g["bsdf_in"][:, 0], (1, 2))
+    assert_bits_equal(got[delta], ref[delta], "delta materials")
+    portable = O.batch("orc_bsdf_sample", g["bsdf_in"], 10, extra=(O.C.c_int32(O.MATH_PORTABLE),))
+    assert_bits_equal(got, portable, "all materials vs oracle")
+    assert np.array_equal(got[:, 0], ref[:, 0])
+    assert np.abs(got[:, 1:8] - ref[:, 1:8]).max() < 1e-14
+
+
+def _open(rt, scene_opener, entry):
+    scene = scene_opener(entry)
+    return scene, rt.Tracer(scene), O.Oracle(scene)
+
+
+def test_device_emission_matches_oracle_and_reference(rt, golden, manifest, scene_opener):
+    entry = manifest["emit"]
+    g = golden("emit")
+    scene, tracer, orc = _open(rt, scene_opener, entry)
+    n = entry["n"]
+    draws_per_photon = {0: 5, 1: 5, 2: 3, 3: 4}
+    for light in range(scene.desc.light_count):
+        # rebuild the 5-per-photon draw tape from the reference's sequential stream
+        desc = scene.desc.lights[light]
+        k = draws_per_photon[desc.type]
+        if desc.type in (0, 1) and desc.inner_radius <= 0:
+            k = 2
+        if desc.type == 2 and desc.radius <= 0:
+            k = 0
+        tape = np.zeros((n, 5))
+        if k:
+            tape[:, :k] = g[f"emit_L{light}_draws"][:n * k].reshape(n, k)
+        rays, colors = tracer.emit(light, tape, n)
+        o_rays, o_colors = orc.emit(light, tape, n, O.MATH_PORTABLE)
+        assert_bits_equal(rays, o_rays, f"light {light} rays vs oracle")
+        assert_bits_equal(colors, o_colors, f"light {light} colors vs oracle")
+        assert_bits_equal(colors, g[f"emit_L{light}_color"], f"light {light} colors vs reference")
+        assert np.abs(rays - g[f"emit_L{light}_rays"]).max() < 1e-12  # sin/cos differ by <= 1 ulp
+
+
+def test_closest_hit_on_reference_rays(rt, golden, manifest, scene_opener):
+    """Cast the reference walk's own rays: hit position/normal/distance bits, volume,
+    triangle id and material equal the reference's (north star: bit-exact hit ids)."""
+    for key in ("walk_furnace", "walk_mixed"):
+        g = golden(key)
+        scene, tracer, orc = _open(rt, scene_opener, manifest[key])
+        f64, i32 = g["walk_bounce_f64"], g["walk_bounce_i32"]
+        origins = np.zeros((f64.shape[0], 3))
+        # a bounce's ray starts at the previous bounce's position (or the emitted origin)
+        emitted = g["walk_emitted"]
+        first = i32[:, 1] == 0
+        photon_row = i32[:, 0]
+        origins[first] = emitted[photon_row[first], :3]
+        origins[~first] = f64[np.where(~first)[0] - 1, :3]
+        rays = np.concatenate([origins, f64[:, 7:10]], axis=1)
+        got_f, got_i = tracer.cast_rays(rays)
+        assert (got_i[:, 0] == 1).all()
+        assert_bits_equal(got_f, f64[:, :7], f"{key} hits")
+        assert np.array_equal(got_i[:, 1], i32[:, 2]) and np.array_equal(got_i[:, 3], i32[:, 4])
+        unambiguous = i32[:, 5] <= 1
+        assert np.array_equal(got_i[unambiguous, 2], i32[unambiguous, 3]), "triangle ids"
+        o_f, o_i = orc.cast_rays(rays)
+        assert_bits_equal(got_f, o_f, f"{key} vs oracle")
+        assert np.array_equal(got_i, o_i)
+
+
+SCENES = {
+    "furnace": {"scene": "tests/scenes/furnace.json", "photons_per_light": 4000},
+    "mixed": {"scene": "tests/scenes/mixed.json", "photons_per_light": 1500},
+    "cbgmd": {"scene": "scenes/CornellBoxGlassMirrorDiffuse.json", "photons_per_light": 6000},
+    "bombardment": {"scene": "scenes/MirrorBombardment-200M.json", "photons_per_light": 20000},
+    "knot": {"scene": "scenes/MirrorKnot4k.json", "photons_per_light": 5000},
+    "multicam": {"scene": "scenes/MultiCameraTest.json", "photons_per_light": 5000},
+    "singlephoton": {"scene": "scenes/SinglePhotonVerify.json", "photons_per_light": 5000},
+    "mirrordirect": {"scene": "scenes/MirrorDirectTest.json", "photons_per_light": 5000},
+}
+
+
+@pytest.mark.parametrize("name", sorted(SCENES))
+def test_photon_paths_bit_exact_vs_oracle(rt, scene_opener, name):
+    """Every photon's emitted ray, bounce count, per-bounce hit (bits), volume, triangle id,
+    material and carried power equal the oracle's with the same Philox stream."""
+    entry = SCENES[name]
+    scene, tracer, orc = _open(rt, scene_opener, entry)
+    total = entry["photons_per_light"] * scene.desc.light_count
+    tracer.reset()
+    tracer.trace(sink_mode=0, record_photons=total)
+    got = tracer.records()
+    counters = tracer.counters()
+    ref = orc.trace(rng_mode=O.RNG_COUNTER, math_mode=O.MATH_PORTABLE, threads=8, record_photons=total)
+    assert_bits_equal(got["emitted"], ref["emitted"], "emitted")
+    assert np.array_equal(got["casts_valid"], ref["casts_valid"]), "casts / bounce counts"
+    assert_bits_equal(got["bounce_f64"], ref["bounce_f64"], "hits")
+    assert np.array_equal(got["bounce_i32"], ref["bounce_i32"]), "ids"
+    assert_bits_equal(got["bounce_power"], ref["bounce_power"], "power")
+    for k in ("photons", "casts", "bounces", "deposits"):
+        assert counters[k] == ref[k], k
+    assert np.allclose(counters["deposited_power"], ref["deposited_power"], rtol=1e-9)
+
+
+def _sorted_records(store):
+    order = np.lexsort(store.view(np.uint32).T[::-1])
+    return store[order]
+
+
+@pytest.mark.parametrize("name", ["mixed", "cbgmd", "bombardment"])
+def test_probe_sink_store_equals_oracle(rt, scene_opener, name):
+    """Sink A: keep-test + BounceStore.  The store is a multiset (append order is a race in
+    the reference too with > 1 worker): same records bit for bit after sorting; same counters."""
+    entry = SCENES[name]
+    scene, tracer, orc = _open(rt, scene_opener, entry)
+    # probes: the first-bounce positions of a coarse subset of photons (a stand-in for the
+    # camera probe pass: any point set exercises the keep-test identically on both sides)
+    pre = orc.trace(rng_mode=O.RNG_COUNTER, math_mode=O.MATH_PORTABLE, threads=8, record_photons=600)
+    probes = pre["bounce_f64"][:, 0, :3][pre["casts_valid"][:, 1] > 0][::3]
+    keep = 12.0
+    capacity = 1 << 16
+    ref = orc.trace(rng_mode=O.RNG_COUNTER, math_mode=O.MATH_PORTABLE, threads=8, sink_mode=O.SINK_PROBE,
+                    probes=probes, probe_cell_size=keep, keep_radius=keep, store_capacity=capacity)
+    tracer.set_probes(probes, keep, keep, capacity)
+    tracer.reset()
+    tracer.trace(sink_mode=1)
+    c = tracer.counters()
+    assert ref["kept"] > 0 and ref["culled"] > 0
+    for k in ("kept", "culled", "store_attempted", "store_size", "store_dropped", "deposits"):
+        assert c[k] == ref[k], k
+    assert_bits_equal(_sorted_records(tracer.store()), _sorted_records(ref["store"]), "store records")
+    # overflow: capacity below the kept count drops the excess and reports it
+    small = max(1, ref["kept"] // 3)
+    tracer.set_probes(probes, keep, keep, small)
+    tracer.reset()
+    tracer.trace(sink_mode=1)
+    c = tracer.counters()
+    assert c["store_size"] == small and c["store_dropped"] == ref["kept"] - small and c["store_attempted"] == ref["kept"]
+
+
+@pytest.mark.parametrize("name", ["mixed", "multicam", "cbgmd"])
+def test_splat_sink_equals_oracle(rt, scene_opener, name):
+    """Sink B: direct camera splat (+ density grid).  Buffers are float-atomic sums, so they
+    are compared to 1e-5 of the image's peak; counters are exact."""
+    entry = dict(SCENES[name])
+    scene, tracer, orc = _open(rt, scene_opener, entry)
+    d = orc.derive()
+    ref = orc.trace(rng_mode=O.RNG_COUNTER, math_mode=O.MATH_PORTABLE, threads=8, sink_mode=O.SINK_SPLAT,
+                    min_splat_radius=d["min_splat_radius"], density_cell_size=d["cell_size"])
+    tracer.set_splat(d["min_splat_radius"], d["cell_size"], 1 << 18)
+    tracer.reset()
+    tracer.trace(sink_mode=2)
+    c = tracer.counters()
+    for k in ("splat_total", "splat_radius_clamped", "splat_luminance_clamped", "deposits", "density_cells",
+              "density_deposits"):
+        assert c[k] == ref[k], k
+    assert ref["splat_total"] > 0
+    for cam, expected in enumerate(ref["splat"]):
+        got = tracer.camera_buffer(cam)
+        assert np.array_equal(got > 0, expected > 0), f"camera {cam}: lit pixel sets differ"
+        assert np.abs(got - expected).max() <= 1e-5 * max(expected.max(), 1e-30), f"camera {cam}"
+    keys, power, counts = tracer.density()
+    assert keys.shape[0] == ref["density_cells"] and int(counts.sum()) == ref["density_deposits"]
+    assert np.allclose(power.astype(np.float64).sum(0), ref["deposited_power"], rtol=1e-4)
+
+
+def test_furnace_ledger_at_scale(rt, scene_opener):
+    """tests/test_FurnaceLedger.cpp:35-70 at N = 2 M on the GPU: the deposited power equals
+    the closed form Phi (1 - rho^(B+1)) / (1 - rho) and every photon deposits exactly B+1
+    times; photon sub-ranges add up (the multi-GPU partition, tests/test_CountEquivalence.cpp:85-135)."""
+    n = 2_000_000
+    scene, tracer, _ = _open(rt, scene_opener, {"scene": "tests/scenes/furnace.json", "photons_per_light": n})
+    tracer.set_probes(np.zeros((1, 3)), 1e5, 1e5, 8)  # tiny store: everything beyond 8 records is "dropped"
+    tracer.reset()
+    tracer.trace(sink_mode=1)
+    c = tracer.counters()
+    terms = scene.settings.bounce_threshold + 1
+    expected = 100.0 * 4 * np.pi * (1 - 0.5 ** terms) / 0.5
+    assert c["photons"] == n and c["bounces"] == n * terms == c["deposits"] == c["kept"]
+    assert c["culled"] == 0 and c["store_attempted"] == n * terms and c["store_size"] == 8
+    assert abs(c["deposited_power"][0] - expected) / expected < 1e-6
+    # two half ranges accumulate to the same totals
+    tracer.reset()
+    tracer.trace(sink_mode=1, first_photon=0, photon_count=n // 2)
+    tracer.trace(sink_mode=1, first_photon=n // 2, photon_count=n - n // 2)
+    c2 = tracer.counters()
+    assert c2["bounces"] == c["bounces"] and c2["photons"] == n
+    assert abs(c2["deposited_power"][0] - c["deposited_power"][0]) / expected < 1e-9
+
+
+def test_errors_are_codes_not_crashes(rt, scene_opener, tracer_mod):
+    scene, tracer, _ = _open(rt, scene_opener, SCENES["furnace"])
+    with pytest.raises(tracer_mod.TracerError) as e:
+        tracer.trace(sink_mode=1)  # probes not set
+    assert e.value.code == 3
+    with pytest.raises(tracer_mod.TracerError) as e:
+        tracer.camera_buffer  # attribute exists
+        tracer_mod._check(tracer_mod.tracer_lib().rt_read_camera_buffer(tracer._handle, 7, None))
+    assert e.value.code == 1
+    with pytest.raises(tracer_mod.TracerError):
+        rt.Tracer(scene, device=99)
