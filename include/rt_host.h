@@ -31,6 +31,11 @@ rt_settings* rth_scene_settings(rth_scene* scene);
 int rth_scene_write(const rth_scene* scene, const char* path);
 void rth_scene_free(rth_scene* scene);
 
+/* Frame quantities Renderer::renderFrame derives before the photon pass (reference
+ * src/Renderer.cpp:222-274,303-310): out[0] sceneDepthFootprint, [1] density cell
+ * size, [2] minimum splat radius, [3] probe keep radius. */
+int rth_frame_derive(const rt_scene* scene, double out[4]);
+
 #ifdef __cplusplus
 }
 #endif

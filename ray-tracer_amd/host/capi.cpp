@@ -3,6 +3,7 @@
 #include "rt_host.h"
 
 #include "Flatten.h"
+#include "FrameSetup.h"
 #include "SceneLoader.h"
 #include "rt_scene_io.h"
 
@@ -56,5 +57,15 @@ int rth_scene_write(const rth_scene* scene, const char* path)
 }
 
 void rth_scene_free(rth_scene* scene) { delete scene; }
+
+int rth_frame_derive(const rt_scene* scene, double out[4])
+{
+    const FrameDerived d = deriveFrame(*scene);
+    out[0] = d.sceneDepthFootprint;
+    out[1] = d.cellSize;
+    out[2] = d.minSplatRadius;
+    out[3] = d.keepRadius;
+    return 0;
+}
 
 }  // extern "C"

@@ -210,16 +210,23 @@ def test_furnace_ledger_at_scale(rt, scene_opener):
     the closed form Phi (1 - rho^(B+1)) / (1 - rho) and every photon deposits exactly B+1
     times; photon sub-ranges add up (the multi-GPU partition, tests/test_CountEquivalence.cpp:85-135)."""
     n = 2_000_000
-    scene, tracer, _ = _open(rt, scene_opener, {"scene": "tests/scenes/furnace.json", "photons_per_light": n})
+    scene, tracer, orc = _open(rt, scene_opener, {"scene": "tests/scenes/furnace.json", "photons_per_light": n})
     tracer.set_probes(np.zeros((1, 3)), 1e5, 1e5, 8)  # tiny store: everything beyond 8 records is "dropped"
     tracer.reset()
     tracer.trace(sink_mode=1)
     c = tracer.counters()
     terms = scene.settings.bounce_threshold + 1
     expected = 100.0 * 4 * np.pi * (1 - 0.5 ** terms) / 0.5
-    assert c["photons"] == n and c["bounces"] == n * terms == c["deposits"] == c["kept"]
-    assert c["culled"] == 0 and c["store_attempted"] == n * terms and c["store_size"] == 8
-    assert abs(c["deposited_power"][0] - expected) / expected < 1e-6
+    # a handful of photons in ten million leak through a box edge (rounding of the quad
+    # parameter test); the oracle leaks the same ones, so the counts are compared exactly
+    # with it and to 1e-5 with the ideal N (B+1)
+    ref = orc.trace(rng_mode=O.RNG_COUNTER, math_mode=O.MATH_PORTABLE, threads=8)
+    assert c["photons"] == n and c["bounces"] == ref["bounces"] and c["casts"] == ref["casts"]
+    assert c["bounces"] == c["deposits"] == c["kept"] == c["store_attempted"]
+    assert abs(c["bounces"] - n * terms) <= 1e-5 * n * terms
+    assert c["culled"] == 0 and c["store_size"] == 8
+    assert abs(c["deposited_power"][0] - expected) / expected < 1e-5
+    assert abs(c["deposited_power"][0] - ref["deposited_power"][0]) / expected < 1e-9
     # two half ranges accumulate to the same totals
     tracer.reset()
     tracer.trace(sink_mode=1, first_photon=0, photon_count=n // 2)
