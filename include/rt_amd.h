@@ -144,6 +144,23 @@ int32_t rt_read_records(rt_tracer* tracer, uint64_t* recorded, double* emitted, 
 /* ---- function-level entry points (device-executed; host pointers in and out) ----
  * Same row layouts as the reference-generated vectors under tests/golden/. */
 
+/* The probe pass of one camera: ProbeGather::collectGatherPoints (reference
+ * include/ProbeGather.h:96-104, src/ProbeGather.cpp:239-460).  Every `probe_sub_sample`-th
+ * pixel is sampled on the device (one thread per pixel; the records come back in the
+ * reference's pixel-major order).  *count receives the number of gather points; when
+ * rows19 is not NULL the first min(capacity, *count) records are written, 19 doubles each:
+ * px, py, position[3], normal[3], viewDir[3], material (-1: emitter face), throughput[3],
+ * unfoldedPathLength, footprintRadius, sampleTime, sampleWeight.  stats3 (optional)
+ * receives cameraRays, deltaExtensions, misses (reference include/ProbeGather.h:53-64).
+ * The result is cached per camera: a size query followed by a fetch runs the pass once. */
+int32_t rt_collect_gather_points(rt_tracer* tracer, int32_t camera, double* rows19, uint64_t capacity,
+                                 uint64_t* count, uint64_t* stats3);
+
+/* ProbeIndex::anyWithinKeepRadius (reference src/ProbeIndex.cpp:48-83) for n host points
+ * (xyz doubles) against the probes given to rt_set_probes; keep[i] = 1 when a probe lies
+ * within the keep radius.  Used for the emitter deposits of src/ProbeGather.cpp:520-545. */
+int32_t rt_probe_keep_test(rt_tracer* tracer, int64_t n, const double* points, uint8_t* keep);
+
 /* Closest valid hit of world rays against the whole scene (reference
  * src/Worker.cpp:538-573): rays [n][6] -> f64 [n][7] position normal distance,
  * i32 [n][4] hit volume triangle material. */

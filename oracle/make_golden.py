@@ -14,6 +14,7 @@ Fixtures written
     walk_*.npz    seeded one-worker photon walks (per-bounce hit, ids, power; totals;
                   splat buffers) for tests/scenes/{furnace,mixed}.json
     render_furnace.npz   Renderer::renderFrame on the furnace: store ledger, counters
+    probes_*.npz  ProbeGather::collectGatherPoints per camera (19-column records + counters)
 """
 import importlib
 import json
@@ -37,6 +38,9 @@ MANIFEST = {
                    "record": 2000},
     "render_furnace": {"scene": "tests/scenes/furnace.json", "photons_per_light": 3000, "fetch_size": 50000},
     "emit": {"scene": "tests/scenes/mixed.json", "n": 64, "seed": 99},
+    "probes_mixed": {"scene": "tests/scenes/mixed.json"},
+    "probes_bombardment": {"scene": "scenes/MirrorBombardment-200M.json", "image": 96, "probe_sub_sample": 1,
+                           "seed": 11},
 }
 
 
@@ -56,6 +60,14 @@ def write_scene(rt, entry, path):
         s.photons_per_light = entry["photons_per_light"]
     if "fetch_size" in entry:
         s.fetch_size = entry["fetch_size"]
+    if "seed" in entry:
+        s.seeded, s.seed = 1, entry["seed"]
+    if "probe_sub_sample" in entry:
+        s.probe_sub_sample = entry["probe_sub_sample"]
+    if "image" in entry:  # shrink every camera to image x image pixels
+        s.image_width = s.image_height = entry["image"]
+        for c in range(scene.desc.camera_count):
+            scene.desc.cameras[c].width = scene.desc.cameras[c].height = entry["image"]
     scene.write(path)
     scene.close()
 
@@ -112,6 +124,15 @@ def main():
         keep = {k: arrays[k] for k in ("render_counters", "render_ledger", "render_crosscheck")}
         keep["render_store_head"] = arrays["render_store_head"][:4096]
         np.savez_compressed(os.path.join(GOLDEN, "render_furnace.npz"), **keep)
+
+        # ---- probe pass ----
+        for key in ("probes_mixed", "probes_bombardment"):
+            scene_path = os.path.join(tmp, key + ".rtsb")
+            write_scene(rt, MANIFEST[key], scene_path)
+            d = os.path.join(tmp, key)
+            os.makedirs(d)
+            run(REFDUMP, "probes", scene_path, d)
+            np.savez_compressed(os.path.join(GOLDEN, key + ".npz"), **load_dir(d))
 
     total = sum(os.path.getsize(os.path.join(GOLDEN, f)) for f in os.listdir(GOLDEN))
     print(f"golden fixtures: {total / 1e6:.2f} MB in {GOLDEN}")

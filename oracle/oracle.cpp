@@ -1506,6 +1506,431 @@ void traceCounterRange(const TraceShared& sh, std::uint64_t first, std::uint64_t
 
 }  // namespace
 
+
+// ------------------------------------------------------------------ probe pass
+// ProbeGather::collectGatherPoints and its helpers (src/ProbeGather.cpp:26-229,239-460,
+// 730-853), EmitterPatch (src/EmitterPatch.cpp), Camera::buildPrimaryRay
+// (src/Camera.cpp:333-493).
+namespace
+{
+
+constexpr int kMaxSpecularDepth = 8;
+constexpr double kReflectionEpsilon = 1e-3;
+constexpr int kCameraSamplesPerPixel = 16;
+constexpr int kEmitterMaterial = -1;
+
+struct EmitterPatch
+{
+    Vec center, right, up, normal;
+    Color radiance;
+    double halfWidth = 0.0, halfHeight = 0.0, radius = 0.0;
+    bool isDisc = false;
+};
+
+// src/EmitterPatch.cpp:15-53 with AreaLight::surfaceRadiance (src/AreaLight.cpp:80-104)
+std::vector<EmitterPatch> collectEmitterPatches(const orc_context& ctx)
+{
+    std::vector<EmitterPatch> patches;
+    for (const Light& light : ctx.lights)
+    {
+        if (light.d.type != RT_LIGHT_AREA)
+        {
+            continue;
+        }
+        const double area = light.d.shape == 1 ? kPi * light.d.radius * light.d.radius : light.d.width * light.d.height;
+        Color radiance{};
+        if (area > 0.0)
+        {
+            const double exitance = light.d.luminous_flux / area;
+            const double rad = exitance / kPi;
+            radiance = Color{light.d.color[0], light.d.color[1], light.d.color[2]} * static_cast<float>(rad);
+        }
+        if (radiance.red <= 0.0f && radiance.green <= 0.0f && radiance.blue <= 0.0f)
+        {
+            continue;
+        }
+        EmitterPatch patch;
+        patch.center = light.position;
+        patch.right = normalized(rotate(light.rotation, kUnitX));
+        patch.up = normalized(rotate(light.rotation, kUnitY));
+        patch.normal = normalized(rotate(light.rotation, kUnitZ));
+        patch.radiance = radiance;
+        if (light.d.shape == 1)
+        {
+            patch.isDisc = true;
+            patch.radius = light.d.radius;
+        }
+        else
+        {
+            patch.halfWidth = light.d.width * 0.5;
+            patch.halfHeight = light.d.height * 0.5;
+        }
+        patches.push_back(patch);
+    }
+    return patches;
+}
+
+// src/EmitterPatch.cpp:55-88
+bool intersectEmitterPatch(const EmitterPatch& patch, const Ray& ray, double& tOut)
+{
+    const double denom = dot(ray.direction, patch.normal);
+    if (denom >= -kEps)
+    {
+        return false;
+    }
+    const double t = dot(patch.center - ray.origin, patch.normal) / denom;
+    if (t <= kEps)
+    {
+        return false;
+    }
+    const Vec hitPoint = ray.origin + (ray.direction * t);
+    const Vec local = hitPoint - patch.center;
+    const double u = dot(local, patch.right), v = dot(local, patch.up);
+    if (patch.isDisc)
+    {
+        if ((u * u + v * v) > (patch.radius * patch.radius)) return false;
+    }
+    else
+    {
+        if (std::abs(u) > patch.halfWidth || std::abs(v) > patch.halfHeight) return false;
+    }
+    tOut = t;
+    return true;
+}
+
+// firstHit + firstEmitterHit, src/ProbeGather.cpp:57-127
+bool firstHit(const orc_context& ctx, const std::vector<EmitterPatch>& patches, const Ray& ray,
+              std::vector<Hit>& castBuffer, Hit& closest)
+{
+    bool found = castScene(ctx, ray, kEps, castBuffer, closest);
+    if (!patches.empty())
+    {
+        double bestT = std::numeric_limits<double>::infinity();
+        const EmitterPatch* best = nullptr;
+        for (const auto& patch : patches)
+        {
+            double t;
+            if (intersectEmitterPatch(patch, ray, t) && t > kEps && t < bestT)
+            {
+                bestT = t;
+                best = &patch;
+            }
+        }
+        if (best && std::isfinite(bestT) && (!found || bestT < closest.distance))
+        {
+            closest = Hit{};
+            closest.position = ray.origin + ray.direction * bestT;
+            closest.normal = best->normal;
+            closest.distance = bestT;
+            closest.material = kEmitterMaterial;
+            found = true;
+        }
+    }
+    return found;
+}
+
+// Camera::buildPrimaryRay, src/Camera.cpp:404-493 (static pose).
+template <class M, class R>
+Ray buildPrimaryRay(const Camera& cam, size_t px, size_t py, R* rng)
+{
+    double offX = 0.5, offY = 0.5;
+    if (rng)
+    {
+        offX = rng->value(1.0);
+        offY = rng->value(1.0);
+    }
+    const double u = (static_cast<double>(px) + offX) / static_cast<double>(cam.d.width);
+    const double v = (static_cast<double>(py) + offY) / static_cast<double>(cam.d.height);
+    const double sx = 2.0 * u - 1.0, sy = 2.0 * v - 1.0;
+    const double halfHeight = cam.halfHeight, aspect = cam.aspect;
+    const Vec &right = cam.right, &up = cam.up, &forward = cam.forward, &eye = cam.position;
+    if (cam.d.projection == RT_PROJECTION_ORTHOGRAPHIC)
+    {
+        const double halfH = cam.d.orthographic_height / 2.0;
+        const Vec origin = eye + (right * (sx * aspect * halfH)) + (up * (sy * halfH));
+        return {origin, normalized(forward)};
+    }
+    if (cam.d.projection == RT_PROJECTION_REALLENS)
+    {
+        const Vec pinholeDir = normalized(forward + (right * (sx * aspect * halfHeight)) + (up * (sy * halfHeight)));
+        const double cosToAxis = dot(pinholeDir, forward);
+        const double t = (cosToAxis > 1e-9) ? (cam.d.focus_distance / cosToAxis) : cam.d.focus_distance;
+        const Vec focusPoint = eye + (pinholeDir * t);
+        double lensX = 0.0, lensY = 0.0;
+        if (rng)
+        {
+            const double r = cam.d.aperture_radius * std::sqrt(rng->value(1.0));
+            const double theta = rng->value(kPi2);
+            lensX = r * M::cos(theta);
+            lensY = r * M::sin(theta);
+        }
+        const Vec aperturePoint = eye + (right * lensX) + (up * lensY);
+        return {aperturePoint, normalized(focusPoint - aperturePoint)};
+    }
+    const Vec direction = forward + (right * (sx * aspect * halfHeight)) + (up * (sy * halfHeight));
+    return {eye, normalized(direction)};
+}
+
+struct ExtendResult  // src/ProbeGather.cpp:138-147
+{
+    Hit hit;
+    Color throughput{1.0f, 1.0f, 1.0f};
+    double unfoldedPathLength = 0.0;
+    Vec finalDirection;
+    bool traversedDelta = false, valid = false;
+};
+
+// src/ProbeGather.cpp:154-229
+template <class M, class R>
+ExtendResult extendAndRecord(const orc_context& ctx, const std::vector<EmitterPatch>& patches,
+                             std::vector<Hit>& castBuffer, R& rng, Ray ray)
+{
+    ExtendResult out;
+    for (int depth = 0; depth < kMaxSpecularDepth; ++depth)
+    {
+        Hit hit;
+        if (!firstHit(ctx, patches, ray, castBuffer, hit))
+        {
+            return out;
+        }
+        out.unfoldedPathLength += hit.distance;
+        if (hit.material == kEmitterMaterial)
+        {
+            out.hit = hit;
+            out.finalDirection = ray.direction;
+            out.valid = true;
+            return out;
+        }
+        const Material& material = ctx.materials[hit.material];
+        if (!material.isDelta())
+        {
+            out.hit = hit;
+            out.finalDirection = ray.direction;
+            out.valid = true;
+            return out;
+        }
+        out.traversedDelta = true;
+        const BSDFSample s = sampleMaterial<M>(material, ray.direction, hit.normal, rng);
+        if (!s.valid)
+        {
+            return out;
+        }
+        out.throughput = out.throughput * s.weight;
+        const Vec nextDir = normalized(s.direction);
+        const double nDotDir = dot(nextDir, hit.normal);
+        const Vec offsetNormal = (nDotDir >= 0.0) ? hit.normal : (hit.normal * -1.0);
+        ray = Ray{hit.position + offsetNormal * kReflectionEpsilon, nextDir};
+    }
+    return out;
+}
+
+// src/ProbeGather.cpp:740-793
+template <class M>
+double pixelFootprintRadius(const Camera& cam, size_t px, size_t py, const Hit& hit, double fallbackDistance)
+{
+    const size_t width = static_cast<size_t>(cam.d.width);
+    const size_t nx = (px + 1 < width) ? px + 1 : (px > 0) ? px - 1 : px;
+    const Ray adjRay = buildPrimaryRay<M, MtRng>(cam, nx, py, nullptr);
+    const double perpRadius = fallbackDistance * cam.tanPixelHalfAngle;
+    const double denom = dot(adjRay.direction, hit.normal);
+    if (std::abs(denom) > kEps)
+    {
+        const double t = dot(hit.position - adjRay.origin, hit.normal) / denom;
+        if (t > kEps)
+        {
+            const Vec adjHit = adjRay.origin + adjRay.direction * t;
+            const double diffRadius = 0.5 * magnitude(adjHit - hit.position);
+            if (diffRadius > 0.0)
+            {
+                return std::min(diffRadius, perpRadius);
+            }
+        }
+    }
+    return perpRadius;
+}
+
+// src/ProbeGather.cpp:818-853
+double reflectedFootprintRadius(double tanPixelHalfAngle, double unfoldedPathLength, const Vec& viewer, const Hit& hit,
+                                const Vec* adjacentReflectedHit)
+{
+    const double viewerMag = magnitude(viewer);
+    double perpFootprint = unfoldedPathLength * tanPixelHalfAngle;
+    if (viewerMag > kEps)
+    {
+        const double cosView = dot(viewer / viewerMag, hit.normal);
+        if (cosView > 0.0)
+        {
+            perpFootprint /= std::min(1.0, std::max(0.5, cosView));
+        }
+    }
+    if (adjacentReflectedHit != nullptr)
+    {
+        const double diffRadius = 0.5 * magnitude(*adjacentReflectedHit - hit.position);
+        if (diffRadius > 0.0)
+        {
+            return std::min(diffRadius, perpFootprint);
+        }
+    }
+    return perpFootprint;
+}
+
+struct GatherPoint  // include/ProbeGather.h:66-79
+{
+    size_t px = 0, py = 0;
+    Vec position, normal, viewDir;
+    int material = 0;
+    Color throughput{1.0f, 1.0f, 1.0f};
+    double unfoldedPathLength = 0.0, footprintRadius = 0.0;
+    float sampleTime = 0.0f, sampleWeight = 1.0f;
+};
+
+// One pixel of ProbeGather::collectGatherPoints, src/ProbeGather.cpp:286-457.  `rng` is
+// the pass-wide sequential stream in mt mode and the pixel's own Philox stream in counter
+// mode; `makeAdjacentRng` yields the fresh generator the adjacent-pixel walk uses (:411).
+template <class M, class R, class MakeAdj>
+void collectPixel(const orc_context& ctx, const Camera& cam, const std::vector<EmitterPatch>& patches, size_t px,
+                  size_t py, R& rng, MakeAdj&& makeAdjacentRng, std::vector<Hit>& castBuffer,
+                  std::vector<GatherPoint>& points, std::uint64_t counts[3])
+{
+    const float frameTime = static_cast<float>(ctx.settings.frame_time);
+    const float shutterSpan = std::max(0.0f, static_cast<float>(ctx.settings.shutter_time));
+    const int cameraSamples = ctx.settings.camera_time_samples;
+    const bool motionActive = (shutterSpan > 0.0f) && (cameraSamples > 1);
+    const bool dofActive = (cam.d.projection == RT_PROJECTION_REALLENS) && (cam.d.aperture_radius > 0.0);
+    const int motionSamples = motionActive ? cameraSamples : 1;
+    const int dofSamples = dofActive ? kCameraSamplesPerPixel : 1;
+    const int primarySamples = std::max(dofSamples, motionSamples);
+    const size_t width = static_cast<size_t>(cam.d.width);
+    const size_t begin = points.size();
+
+    for (int primary = 0; primary < primarySamples; ++primary)
+    {
+        const float sampleTime = motionActive ? frameTime + static_cast<float>(rng.value(shutterSpan)) : frameTime;
+        const Ray ray = dofActive ? buildPrimaryRay<M>(cam, px, py, &rng) : buildPrimaryRay<M, R>(cam, px, py, nullptr);
+        ++counts[0];
+        Hit first;
+        if (!firstHit(ctx, patches, ray, castBuffer, first))
+        {
+            ++counts[2];
+            continue;
+        }
+        const bool firstIsEmitter = first.material == kEmitterMaterial;
+        if (firstIsEmitter || !ctx.materials[first.material].isDelta())
+        {
+            GatherPoint gp;
+            gp.px = px;
+            gp.py = py;
+            gp.position = first.position;
+            gp.normal = first.normal;
+            gp.viewDir = normalized(ray.origin - first.position);
+            gp.material = first.material;
+            gp.unfoldedPathLength = first.distance;
+            gp.footprintRadius = pixelFootprintRadius<M>(cam, px, py, first, first.distance);
+            gp.sampleTime = sampleTime;
+            points.push_back(gp);
+            continue;
+        }
+        const bool stochasticDelta = ctx.materials[first.material].type == RT_MATERIAL_DIELECTRIC;
+        const int extensionSamples = (stochasticDelta && !dofActive) ? kCameraSamplesPerPixel : 1;
+        for (int ext = 0; ext < extensionSamples; ++ext)
+        {
+            const ExtendResult chain = extendAndRecord<M>(ctx, patches, castBuffer, rng, ray);
+            if (chain.traversedDelta) ++counts[1];
+            if (!chain.valid)
+            {
+                ++counts[2];
+                continue;
+            }
+            const Vec reflectedView = -chain.finalDirection;
+            Vec adjReflectedHit;
+            bool haveAdj = false;
+            if (!stochasticDelta)
+            {
+                const size_t adjX = (px + 1 < width) ? px + 1 : (px > 0) ? px - 1 : px;
+                if (adjX != px)
+                {
+                    const Ray adjRay = dofActive ? buildPrimaryRay<M>(cam, adjX, py, &rng)
+                                                 : buildPrimaryRay<M, R>(cam, adjX, py, nullptr);
+                    auto adjRng = makeAdjacentRng();
+                    const ExtendResult adjChain = extendAndRecord<M>(ctx, patches, castBuffer, adjRng, adjRay);
+                    if (adjChain.valid && adjChain.hit.material == chain.hit.material &&
+                        dot(adjChain.hit.normal, chain.hit.normal) >= 0.5)
+                    {
+                        adjReflectedHit = adjChain.hit.position;
+                        haveAdj = true;
+                    }
+                }
+            }
+            GatherPoint gp;
+            gp.px = px;
+            gp.py = py;
+            gp.position = chain.hit.position;
+            gp.normal = chain.hit.normal;
+            gp.viewDir = normalized(reflectedView);
+            gp.material = chain.hit.material;
+            gp.throughput = chain.throughput;
+            gp.unfoldedPathLength = chain.unfoldedPathLength;
+            gp.footprintRadius = reflectedFootprintRadius(cam.tanPixelHalfAngle, chain.unfoldedPathLength, reflectedView,
+                                                          chain.hit, haveAdj ? &adjReflectedHit : nullptr);
+            gp.sampleTime = sampleTime;
+            points.push_back(gp);
+        }
+    }
+    const size_t survived = points.size() - begin;
+    if (survived > 0)
+    {
+        const float w = 1.0f / static_cast<float>(survived);
+        for (size_t i = begin; i < points.size(); ++i)
+        {
+            points[i].sampleWeight = w;
+        }
+    }
+}
+
+constexpr std::uint32_t kProbeStreamTag = 0xFFFFFFFFu;  // "light id" of the camera-side Philox streams
+
+template <class M>
+std::vector<GatherPoint> collectGatherPoints(const orc_context& ctx, int cameraIndex, int rngMode,
+                                             std::uint64_t counts[3])
+{
+    const Camera& cam = ctx.cameras[cameraIndex];
+    const std::vector<EmitterPatch> patches = collectEmitterPatches(ctx);
+    std::vector<GatherPoint> points;
+    std::vector<Hit> castBuffer;
+    const size_t stride = std::max<size_t>(1, ctx.settings.probe_sub_sample);
+    // probeSeed, src/Renderer.cpp:92-100 (truncated to 32 bits by the RandomGenerator constructor)
+    const std::uint32_t baseSeed = ctx.settings.seeded ? ctx.settings.seed : 0u;
+    const std::uint32_t probeSeed = static_cast<std::uint32_t>(static_cast<long long>(baseSeed) + 0x9E3779B9LL);
+    MtRng mt(probeSeed);
+    for (size_t y = 0; y < static_cast<size_t>(cam.d.height); y += stride)
+    {
+        for (size_t x = 0; x < static_cast<size_t>(cam.d.width); x += stride)
+        {
+            if (rngMode == ORC_RNG_MT)
+            {
+                collectPixel<M>(ctx, cam, patches, x, y, mt, []() { return MtRng(0xC0FFEEu); }, castBuffer, points,
+                                counts);
+            }
+            else
+            {
+                CounterRng rng(probeSeed);
+                rng.begin(kProbeStreamTag, static_cast<std::uint64_t>(cameraIndex) << 40 |
+                                               (static_cast<std::uint64_t>(y) * cam.d.width + x), 0);
+                collectPixel<M>(ctx, cam, patches, x, y, rng,
+                                []() {
+                                    CounterRng adj(0xC0FFEEu);
+                                    adj.begin(kProbeStreamTag, 0, 0);
+                                    return adj;
+                                },
+                                castBuffer, points, counts);
+            }
+        }
+    }
+    return points;
+}
+
+}  // namespace
+
 // ------------------------------------------------------------------ C interface
 extern "C" {
 
@@ -1989,10 +2414,35 @@ void orc_emit_mt(const orc_context* ctx, std::int32_t light, std::int64_t n, std
     }
 }
 
-std::int64_t orc_collect_gather_points(orc_context*, std::int32_t, std::int32_t, std::int32_t, const double** rows)
+std::int64_t orc_collect_gather_points(orc_context* ctx, std::int32_t camera, std::int32_t rng_mode,
+                                       std::int32_t math_mode, const double** rows)
 {
     *rows = nullptr;
-    return 0;
+    if (camera < 0 || static_cast<size_t>(camera) >= ctx->cameras.size())
+    {
+        return -1;
+    }
+    std::uint64_t counts[3] = {0, 0, 0};
+    const std::vector<GatherPoint> points = (math_mode == ORC_MATH_LIBM)
+                                                ? collectGatherPoints<LibmMath>(*ctx, camera, rng_mode, counts)
+                                                : collectGatherPoints<PortableMath>(*ctx, camera, rng_mode, counts);
+    ctx->gatherRows.clear();
+    ctx->gatherRows.reserve(points.size() * 19 + 3);
+    for (const GatherPoint& gp : points)
+    {
+        const double row[19] = {static_cast<double>(gp.px), static_cast<double>(gp.py),
+                                gp.position.x, gp.position.y, gp.position.z,
+                                gp.normal.x, gp.normal.y, gp.normal.z,
+                                gp.viewDir.x, gp.viewDir.y, gp.viewDir.z,
+                                static_cast<double>(gp.material),
+                                gp.throughput.red, gp.throughput.green, gp.throughput.blue,
+                                gp.unfoldedPathLength, gp.footprintRadius, gp.sampleTime, gp.sampleWeight};
+        ctx->gatherRows.insert(ctx->gatherRows.end(), row, row + 19);
+    }
+    // camera rays, delta extensions, misses follow the rows
+    for (int i = 0; i < 3; ++i) ctx->gatherRows.push_back(static_cast<double>(counts[i]));
+    *rows = ctx->gatherRows.data();
+    return static_cast<std::int64_t>(points.size());
 }
 
 }  // extern "C"

@@ -161,6 +161,16 @@ struct rt_tracer
     DeviceArray<int32_t> recCasts, recI32;
     DeviceArray<float> recPower;
 
+    // probe pass
+    DeviceArray<rtd::EmitterPatch> patches;
+    struct GatherCache
+    {
+        bool valid = false;
+        std::vector<rtd::GatherPoint> points;
+        uint64_t stats[3] = {0, 0, 0};
+    };
+    std::vector<GatherCache> gatherCache;
+
     rtd::SceneView view{};
     int blocks = 0;
 };
@@ -320,12 +330,71 @@ void buildScene(rt_tracer* t, const rt_scene* scene)
         c.height = rc.height;
         c.bounceFilter = rc.bounce_filter;
         c.lightFilter = rc.light_filter;
+        c.projection = rc.projection;
+        c.orthographicHeight = rc.orthographic_height;
+        c.apertureRadius = rc.aperture_radius;
+        c.focusDistance = rc.focus_distance;
         c.windowStart = windowStart;
         c.windowEnd = windowEnd;
         t->cameraBuffers[i]->allocate(static_cast<size_t>(rc.width) * rc.height * 3);
         c.buffer = t->cameraBuffers[i]->ptr;
         t->cameraHost.push_back(c);
     }
+
+    // ---- emitter patches: the lit face of every area light with positive radiance
+    //      (reference src/EmitterPatch.cpp:15-53, AreaLight::surfaceRadiance src/AreaLight.cpp:80-104) ----
+    std::vector<rtd::EmitterPatch> patches;
+    for (int64_t i = 0; i < scene->light_count; ++i)
+    {
+        const rt_light& rl = scene->lights[i];
+        if (rl.type != RT_LIGHT_AREA)
+        {
+            continue;
+        }
+        const double area = rl.shape == 1 ? M_PI * rl.radius * rl.radius : rl.width * rl.height;
+        float radiance[3] = {0.0f, 0.0f, 0.0f};
+        if (area > 0.0)
+        {
+            const double exitance = rl.luminous_flux / area;
+            const float rad = static_cast<float>(exitance / M_PI);
+            for (int k = 0; k < 3; ++k)
+            {
+                radiance[k] = rl.color[k] * rad;
+            }
+        }
+        if (radiance[0] <= 0.0f && radiance[1] <= 0.0f && radiance[2] <= 0.0f)
+        {
+            continue;
+        }
+        rtd::EmitterPatch patch{};
+        std::memcpy(patch.center, rl.position, sizeof(patch.center));
+        const double axes[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+        double* outs[3] = {patch.right, patch.up, patch.normal};
+        for (int a = 0; a < 3; ++a)
+        {
+            double r[3];
+            hostRotate(rl.rotation, axes[a], r);
+            const double m = std::sqrt((r[0] * r[0] + r[1] * r[1]) + r[2] * r[2]);
+            for (int k = 0; k < 3; ++k)
+            {
+                outs[a][k] = r[k] / m;
+            }
+        }
+        std::memcpy(patch.radiance, radiance, sizeof(radiance));
+        if (rl.shape == 1)
+        {
+            patch.isDisc = 1;
+            patch.radius = rl.radius;
+        }
+        else
+        {
+            patch.halfWidth = rl.width * 0.5;
+            patch.halfHeight = rl.height * 0.5;
+        }
+        patches.push_back(patch);
+    }
+    t->patches.upload(patches);
+    t->gatherCache.assign(static_cast<size_t>(scene->camera_count), rt_tracer::GatherCache{});
 
     t->volumes.upload(volumes);
     t->nodes.upload(nodes);
@@ -358,6 +427,13 @@ void buildScene(rt_tracer* t, const rt_scene* scene)
     view.windowStart = windowStart;
     view.windowEnd = windowEnd;
     view.hasCamera = scene->camera_count > 0 ? 1 : 0;
+    view.patches = t->patches.ptr;
+    view.patchCount = static_cast<int32_t>(patches.size());
+    view.frameTime = start;
+    view.shutterSpan = std::max(0.0f, shutter);
+    view.cameraTimeSamples = scene->settings.camera_time_samples;
+    // probeSeed: base seed + 0x9E3779B9, truncated to 32 bits (reference src/Renderer.cpp:92-100)
+    view.probeSeed = static_cast<uint32_t>(static_cast<long long>(view.seed) + 0x9E3779B9LL);
 }
 
 void resetState(rt_tracer* t)
@@ -859,6 +935,125 @@ int32_t rt_read_records(rt_tracer* tracer, uint64_t* recorded, double* emitted, 
         fetch(bounce_f64, tracer->recF64.ptr, tracer->recF64.count * sizeof(double));
         fetch(bounce_i32, tracer->recI32.ptr, tracer->recI32.count * sizeof(int32_t));
         fetch(bounce_power, tracer->recPower.ptr, tracer->recPower.count * sizeof(float));
+    });
+}
+
+int32_t rt_collect_gather_points(rt_tracer* tracer, int32_t camera, double* rows19, uint64_t capacity,
+                                 uint64_t* count, uint64_t* stats3)
+{
+    return guarded([&]() {
+        require(tracer != nullptr, "tracer is null");
+        require(camera >= 0 && camera < static_cast<int32_t>(tracer->cameraHost.size()), "camera index out of range");
+        require(count != nullptr, "count is null");
+        activate(tracer);
+        rt_tracer::GatherCache& cache = tracer->gatherCache[static_cast<size_t>(camera)];
+        if (!cache.valid)
+        {
+            const rtd::Camera& cam = tracer->cameraHost[camera];
+            const int32_t stride = static_cast<int32_t>(std::max<uint64_t>(1, tracer->settings.probe_sub_sample));
+            const int64_t gw = (cam.width + stride - 1) / stride, gh = (cam.height + stride - 1) / stride;
+            const int64_t pixels = gw * gh;
+            DeviceArray<uint32_t> counts;
+            DeviceArray<unsigned long long> stats;
+            DeviceArray<uint64_t> offsets;
+            DeviceArray<rtd::GatherPoint> points;
+            counts.allocate(static_cast<size_t>(pixels));
+            stats.allocate(3);
+            counts.zero(tracer->stream);
+            stats.zero(tracer->stream);
+            rtd::launchGatherCount(tracer->view, camera, stride, pixels, counts.ptr, stats.ptr, tracer->stream);
+            check(hipGetLastError(), "gather count launch");
+            std::vector<uint32_t> hostCounts(static_cast<size_t>(pixels));
+            check(hipMemcpyAsync(hostCounts.data(), counts.ptr, hostCounts.size() * sizeof(uint32_t),
+                                 hipMemcpyDeviceToHost, tracer->stream),
+                  "hipMemcpyAsync counts");
+            unsigned long long hostStats[3] = {0, 0, 0};
+            check(hipMemcpyAsync(hostStats, stats.ptr, sizeof(hostStats), hipMemcpyDeviceToHost, tracer->stream),
+                  "hipMemcpyAsync stats");
+            check(hipStreamSynchronize(tracer->stream), "hipStreamSynchronize");
+            std::vector<uint64_t> hostOffsets(hostCounts.size());
+            uint64_t total = 0;
+            for (size_t i = 0; i < hostCounts.size(); ++i)
+            {
+                hostOffsets[i] = total;
+                total += hostCounts[i];
+            }
+            cache.points.assign(static_cast<size_t>(total), rtd::GatherPoint{});
+            if (total > 0)
+            {
+                offsets.upload(hostOffsets);
+                points.allocate(static_cast<size_t>(total));
+                rtd::launchGatherWrite(tracer->view, camera, stride, pixels, counts.ptr, offsets.ptr, points.ptr,
+                                       tracer->stream);
+                check(hipGetLastError(), "gather write launch");
+                check(hipMemcpyAsync(cache.points.data(), points.ptr, total * sizeof(rtd::GatherPoint),
+                                     hipMemcpyDeviceToHost, tracer->stream),
+                      "hipMemcpyAsync gather points");
+                check(hipStreamSynchronize(tracer->stream), "hipStreamSynchronize");
+            }
+            for (int k = 0; k < 3; ++k)
+            {
+                cache.stats[k] = hostStats[k];
+            }
+            cache.valid = true;
+        }
+        *count = cache.points.size();
+        if (stats3 != nullptr)
+        {
+            std::memcpy(stats3, cache.stats, sizeof(cache.stats));
+        }
+        if (rows19 != nullptr)
+        {
+            const uint64_t n = std::min<uint64_t>(capacity, cache.points.size());
+            for (uint64_t i = 0; i < n; ++i)
+            {
+                const rtd::GatherPoint& g = cache.points[i];
+                double* r = rows19 + 19 * i;
+                r[0] = g.px;
+                r[1] = g.py;
+                for (int k = 0; k < 3; ++k)
+                {
+                    r[2 + k] = g.position[k];
+                    r[5 + k] = g.normal[k];
+                    r[8 + k] = g.viewDir[k];
+                    r[12 + k] = g.throughput[k];
+                }
+                r[11] = g.material;
+                r[15] = g.unfoldedPathLength;
+                r[16] = g.footprintRadius;
+                r[17] = g.sampleTime;
+                r[18] = g.sampleWeight;
+            }
+        }
+    });
+}
+
+int32_t rt_probe_keep_test(rt_tracer* tracer, int64_t n, const double* points, uint8_t* keep)
+{
+    return guarded([&]() {
+        require(tracer != nullptr, "tracer is null");
+        require(n >= 0 && (n == 0 || (points != nullptr && keep != nullptr)), "bad arguments");
+        if (!tracer->probesSet)
+        {
+            throw ApiError(RT_ERR_STATE, "rt_set_probes must be called before rt_probe_keep_test");
+        }
+        if (n == 0)
+        {
+            return;
+        }
+        activate(tracer);
+        DeviceArray<double> in;
+        DeviceArray<uint8_t> out;
+        in.allocate(static_cast<size_t>(3 * n));
+        out.allocate(static_cast<size_t>(n));
+        check(hipMemcpyAsync(in.ptr, points, static_cast<size_t>(3 * n) * sizeof(double), hipMemcpyHostToDevice,
+                             tracer->stream),
+              "hipMemcpyAsync points");
+        rtd::launchProbeTest(tracer->probeView, n, in.ptr, out.ptr, tracer->stream);
+        check(hipGetLastError(), "probe test launch");
+        check(hipMemcpyAsync(keep, out.ptr, static_cast<size_t>(n), hipMemcpyDeviceToHost, tracer->stream),
+              "hipMemcpyAsync keep");
+        check(hipStreamSynchronize(tracer->stream), "hipStreamSynchronize");
     });
 }
 

@@ -136,9 +136,30 @@ struct Camera
     double pos[3];
     double right[3], up[3], forward[3];
     double aspect, halfHeight, tanPixelHalfAngle;
-    int32_t width, height, bounceFilter, lightFilter;
+    double orthographicHeight, apertureRadius, focusDistance;
+    int32_t width, height, bounceFilter, lightFilter, projection, pad;
     float windowStart, windowEnd;
     float* buffer;  // [h][w][3]
+};
+
+// A visible area-light face (reference include/EmitterPatch.h, src/EmitterPatch.cpp:15-53).
+struct EmitterPatch
+{
+    double center[3], right[3], up[3], normal[3];
+    double halfWidth, halfHeight, radius;
+    float radiance[3];
+    int32_t isDisc;
+};
+
+// One camera sample that reached a non-delta surface (reference include/ProbeGather.h:66-79).
+struct GatherPoint
+{
+    int32_t px, py;
+    double position[3], normal[3], viewDir[3];
+    double unfoldedPathLength, footprintRadius;
+    float throughput[3];
+    int32_t material;  // -1: emitter face
+    float sampleTime, sampleWeight;
 };
 
 struct SceneView
@@ -151,6 +172,8 @@ struct SceneView
     const Material* materials;
     const Light* lights;
     Camera* cameras;
+    const EmitterPatch* patches;
+    int32_t patchCount, pad0;
     int32_t volumeCount, lightCount, cameraCount, bounceThreshold;
     double terminationThreshold;
     double splatLuminanceClamp;
@@ -158,6 +181,10 @@ struct SceneView
     uint32_t seed;
     float windowStart, windowEnd;  // primary camera's exposure window
     int32_t hasCamera;
+    // probe pass
+    float frameTime, shutterSpan;
+    int32_t cameraTimeSamples;
+    uint32_t probeSeed;
 };
 
 struct Ray
@@ -986,6 +1013,312 @@ RT_DEV Ray emitRay(const Light& l, Rng& rng)
     ray.o = origin;
     ray.d = direction;
     return ray;
+}
+
+
+// ------------------------------------------------------------------ camera side
+// Camera::buildPrimaryRay, reference src/Camera.cpp:333-493 (static pose).
+RT_DEV Ray buildPrimaryRay(const Camera& cam, int32_t px, int32_t py, Rng* rng)
+{
+    double offX = 0.5, offY = 0.5;
+    if (rng)
+    {
+        offX = rng->value(1.0);
+        offY = rng->value(1.0);
+    }
+    const double u = (static_cast<double>(px) + offX) / static_cast<double>(cam.width);
+    const double v = (static_cast<double>(py) + offY) / static_cast<double>(cam.height);
+    const double sx = 2.0 * u - 1.0, sy = 2.0 * v - 1.0;
+    const Vec right = mk(cam.right[0], cam.right[1], cam.right[2]), up = mk(cam.up[0], cam.up[1], cam.up[2]);
+    const Vec forward = mk(cam.forward[0], cam.forward[1], cam.forward[2]), eye = mk(cam.pos[0], cam.pos[1], cam.pos[2]);
+    Ray ray;
+    if (cam.projection == RT_PROJECTION_ORTHOGRAPHIC)
+    {
+        const double halfH = cam.orthographicHeight / 2.0;
+        ray.o = eye + (right * (sx * cam.aspect * halfH)) + (up * (sy * halfH));
+        ray.d = normalized(forward);
+        return ray;
+    }
+    if (cam.projection == RT_PROJECTION_REALLENS)
+    {
+        const Vec pinholeDir =
+            normalized(forward + (right * (sx * cam.aspect * cam.halfHeight)) + (up * (sy * cam.halfHeight)));
+        const double cosToAxis = dot(pinholeDir, forward);
+        const double t = (cosToAxis > 1e-9) ? (cam.focusDistance / cosToAxis) : cam.focusDistance;
+        const Vec focusPoint = eye + (pinholeDir * t);
+        double lensX = 0.0, lensY = 0.0;
+        if (rng)
+        {
+            const double r = cam.apertureRadius * __builtin_sqrt(rng->value(1.0));
+            const double theta = rng->value(kPi2);
+            double st, ct;
+            rt_sincos(theta, &st, &ct);
+            lensX = r * ct;
+            lensY = r * st;
+        }
+        ray.o = eye + (right * lensX) + (up * lensY);
+        ray.d = normalized(focusPoint - ray.o);
+        return ray;
+    }
+    ray.o = eye;
+    ray.d = normalized(forward + (right * (sx * cam.aspect * cam.halfHeight)) + (up * (sy * cam.halfHeight)));
+    return ray;
+}
+
+// firstHit + firstEmitterHit + intersectEmitterPatch, reference src/ProbeGather.cpp:57-127,
+// src/EmitterPatch.cpp:55-88.  material == -1 marks an emitter face.
+RT_DEV bool firstHit(const SceneView& s, const Ray& ray, Hit* closest)
+{
+    bool found = castScene(s, ray, kEps, true, closest);
+    double bestT = __builtin_inf();
+    int32_t best = -1;
+    for (int32_t i = 0; i < s.patchCount; ++i)
+    {
+        const EmitterPatch& patch = s.patches[i];
+        const Vec n = mk(patch.normal[0], patch.normal[1], patch.normal[2]);
+        const Vec center = mk(patch.center[0], patch.center[1], patch.center[2]);
+        const double denom = dot(ray.d, n);
+        if (denom >= -kEps) continue;
+        const double t = dot(center - ray.o, n) / denom;
+        if (t <= kEps) continue;
+        const Vec hitPoint = ray.o + (ray.d * t);
+        const Vec local = hitPoint - center;
+        const double u = dot(local, mk(patch.right[0], patch.right[1], patch.right[2]));
+        const double v = dot(local, mk(patch.up[0], patch.up[1], patch.up[2]));
+        if (patch.isDisc)
+        {
+            if ((u * u + v * v) > (patch.radius * patch.radius)) continue;
+        }
+        else
+        {
+            if (dabs(u) > patch.halfWidth || dabs(v) > patch.halfHeight) continue;
+        }
+        if (t > kEps && t < bestT)
+        {
+            bestT = t;
+            best = i;
+        }
+    }
+    if (best >= 0 && (!found || bestT < closest->distance))
+    {
+        const EmitterPatch& patch = s.patches[best];
+        closest->position = ray.o + ray.d * bestT;
+        closest->normal = mk(patch.normal[0], patch.normal[1], patch.normal[2]);
+        closest->distance = bestT;
+        closest->material = -1;
+        closest->volume = -1;
+        closest->triangle = -1;
+        found = true;
+    }
+    return found;
+}
+
+struct ExtendResult  // reference src/ProbeGather.cpp:138-147
+{
+    Hit hit;
+    Color throughput;
+    double unfoldedPathLength;
+    Vec finalDirection;
+    bool traversedDelta, valid;
+};
+
+// extendAndRecord, reference src/ProbeGather.cpp:154-229
+RT_DEV ExtendResult extendAndRecord(const SceneView& s, Rng& rng, Ray ray)
+{
+    ExtendResult out;
+    out.throughput = Color{1.0f, 1.0f, 1.0f};
+    out.unfoldedPathLength = 0.0;
+    out.finalDirection = mk(0, 0, 0);
+    out.traversedDelta = false;
+    out.valid = false;
+    for (int depth = 0; depth < 8; ++depth)
+    {
+        Hit hit;
+        if (!firstHit(s, ray, &hit))
+        {
+            return out;
+        }
+        out.unfoldedPathLength += hit.distance;
+        bool terminal = hit.material < 0;
+        if (!terminal)
+        {
+            terminal = !materialIsDelta(s.materials[hit.material].type);
+        }
+        if (terminal)
+        {
+            out.hit = hit;
+            out.finalDirection = ray.d;
+            out.valid = true;
+            return out;
+        }
+        out.traversedDelta = true;
+        const BSDFSample smp = sampleMaterial(s.materials[hit.material], ray.d, hit.normal, rng);
+        if (!smp.valid)
+        {
+            return out;
+        }
+        out.throughput = out.throughput * smp.weight;
+        const Vec nextDir = normalized(smp.direction);
+        const double nDotDir = dot(nextDir, hit.normal);
+        const Vec offsetNormal = (nDotDir >= 0.0) ? hit.normal : (hit.normal * -1.0);
+        ray.o = hit.position + offsetNormal * 1e-3;
+        ray.d = nextDir;
+    }
+    return out;
+}
+
+// pixelFootprintRadius, reference src/ProbeGather.cpp:740-793
+RT_DEV double pixelFootprintRadius(const Camera& cam, int32_t px, int32_t py, const Hit& hit, double fallbackDistance)
+{
+    const int32_t nx = (px + 1 < cam.width) ? px + 1 : (px > 0) ? px - 1 : px;
+    const Ray adjRay = buildPrimaryRay(cam, nx, py, nullptr);
+    const double perpRadius = fallbackDistance * cam.tanPixelHalfAngle;
+    const double denom = dot(adjRay.d, hit.normal);
+    if (dabs(denom) > kEps)
+    {
+        const double t = dot(hit.position - adjRay.o, hit.normal) / denom;
+        if (t > kEps)
+        {
+            const Vec adjHit = adjRay.o + adjRay.d * t;
+            const double diffRadius = 0.5 * magnitude(adjHit - hit.position);
+            if (diffRadius > 0.0)
+            {
+                return dmin(diffRadius, perpRadius);
+            }
+        }
+    }
+    return perpRadius;
+}
+
+// reflectedFootprintRadius, reference src/ProbeGather.cpp:818-853
+RT_DEV double reflectedFootprintRadius(double tanPixelHalfAngle, double unfoldedPathLength, const Vec& viewer,
+                                       const Hit& hit, bool haveAdjacent, const Vec& adjacentHit)
+{
+    const double viewerMag = magnitude(viewer);
+    double perpFootprint = unfoldedPathLength * tanPixelHalfAngle;
+    if (viewerMag > kEps)
+    {
+        const double cosView = dot(viewer / viewerMag, hit.normal);
+        if (cosView > 0.0)
+        {
+            perpFootprint /= dmin(1.0, dmax(0.5, cosView));
+        }
+    }
+    if (haveAdjacent)
+    {
+        const double diffRadius = 0.5 * magnitude(adjacentHit - hit.position);
+        if (diffRadius > 0.0)
+        {
+            return dmin(diffRadius, perpFootprint);
+        }
+    }
+    return perpFootprint;
+}
+
+// One pixel of ProbeGather::collectGatherPoints, reference src/ProbeGather.cpp:286-457.
+// Calls emit(point) for every surviving sample, in the reference's order; returns the
+// number of survivors.  stats[0..2] += camera rays, delta extensions, misses.
+template <class Emit>
+RT_DEV int collectPixel(const SceneView& s, int32_t cameraIndex, int32_t px, int32_t py, unsigned long long* stats,
+                        Emit&& emit)
+{
+    const Camera& cam = s.cameras[cameraIndex];
+    const bool motionActive = (s.shutterSpan > 0.0f) && (s.cameraTimeSamples > 1);
+    const bool dofActive = (cam.projection == RT_PROJECTION_REALLENS) && (cam.apertureRadius > 0.0);
+    const int motionSamples = motionActive ? s.cameraTimeSamples : 1;
+    const int dofSamples = dofActive ? 16 : 1;
+    const int primarySamples = dofSamples > motionSamples ? dofSamples : motionSamples;
+    Rng rng;
+    rng.tape = nullptr;
+    rng.next = 0;
+    rng.seed = s.probeSeed;
+    rng.begin(0xFFFFFFFFu,
+              (static_cast<uint64_t>(cameraIndex) << 40) | (static_cast<uint64_t>(py) * cam.width + px), 0);
+    int survived = 0;
+    for (int primary = 0; primary < primarySamples; ++primary)
+    {
+        const float sampleTime =
+            motionActive ? s.frameTime + static_cast<float>(rng.value(static_cast<double>(s.shutterSpan))) : s.frameTime;
+        const Ray ray = buildPrimaryRay(cam, px, py, dofActive ? &rng : nullptr);
+        stats[0] += 1;
+        Hit first;
+        if (!firstHit(s, ray, &first))
+        {
+            stats[2] += 1;
+            continue;
+        }
+        bool direct = first.material < 0;
+        if (!direct)
+        {
+            direct = !materialIsDelta(s.materials[first.material].type);
+        }
+        GatherPoint gp;
+        gp.px = px;
+        gp.py = py;
+        gp.sampleTime = sampleTime;
+        gp.sampleWeight = 1.0f;
+        if (direct)
+        {
+            const Vec view = normalized(ray.o - first.position);
+            gp.position[0] = first.position.x; gp.position[1] = first.position.y; gp.position[2] = first.position.z;
+            gp.normal[0] = first.normal.x; gp.normal[1] = first.normal.y; gp.normal[2] = first.normal.z;
+            gp.viewDir[0] = view.x; gp.viewDir[1] = view.y; gp.viewDir[2] = view.z;
+            gp.material = first.material;
+            gp.throughput[0] = 1.0f; gp.throughput[1] = 1.0f; gp.throughput[2] = 1.0f;
+            gp.unfoldedPathLength = first.distance;
+            gp.footprintRadius = pixelFootprintRadius(cam, px, py, first, first.distance);
+            emit(gp, survived);
+            survived += 1;
+            continue;
+        }
+        const bool stochasticDelta = s.materials[first.material].type == RT_MATERIAL_DIELECTRIC;
+        const int extensionSamples = (stochasticDelta && !dofActive) ? 16 : 1;
+        for (int ext = 0; ext < extensionSamples; ++ext)
+        {
+            const ExtendResult chain = extendAndRecord(s, rng, ray);
+            if (chain.traversedDelta) stats[1] += 1;
+            if (!chain.valid)
+            {
+                stats[2] += 1;
+                continue;
+            }
+            const Vec reflectedView = neg(chain.finalDirection);
+            Vec adjHit = mk(0, 0, 0);
+            bool haveAdj = false;
+            if (!stochasticDelta)
+            {
+                const int32_t adjX = (px + 1 < cam.width) ? px + 1 : (px > 0) ? px - 1 : px;
+                if (adjX != px)
+                {
+                    const Ray adjRay = buildPrimaryRay(cam, adjX, py, dofActive ? &rng : nullptr);
+                    Rng adjRng;
+                    adjRng.tape = nullptr;
+                    adjRng.next = 0;
+                    adjRng.seed = 0xC0FFEEu;
+                    adjRng.begin(0xFFFFFFFFu, 0, 0);
+                    const ExtendResult adjChain = extendAndRecord(s, adjRng, adjRay);
+                    if (adjChain.valid && adjChain.hit.material == chain.hit.material &&
+                        dot(adjChain.hit.normal, chain.hit.normal) >= 0.5)
+                    {
+                        adjHit = adjChain.hit.position;
+                        haveAdj = true;
+                    }
+                }
+            }
+            const Vec view = normalized(reflectedView);
+            gp.position[0] = chain.hit.position.x; gp.position[1] = chain.hit.position.y; gp.position[2] = chain.hit.position.z;
+            gp.normal[0] = chain.hit.normal.x; gp.normal[1] = chain.hit.normal.y; gp.normal[2] = chain.hit.normal.z;
+            gp.viewDir[0] = view.x; gp.viewDir[1] = view.y; gp.viewDir[2] = view.z;
+            gp.material = chain.hit.material;
+            gp.throughput[0] = chain.throughput.r; gp.throughput[1] = chain.throughput.g; gp.throughput[2] = chain.throughput.b;
+            gp.unfoldedPathLength = chain.unfoldedPathLength;
+            gp.footprintRadius = reflectedFootprintRadius(cam.tanPixelHalfAngle, chain.unfoldedPathLength, reflectedView,
+                                                          chain.hit, haveAdj, adjHit);
+            emit(gp, survived);
+            survived += 1;
+        }
+    }
+    return survived;
 }
 
 }  // namespace rtd

@@ -87,5 +87,12 @@ void launchIntersect(int kind, int64_t n, const double* in, void* out, hipStream
 void launchBsdfSample(int64_t n, const double* in14, double* out10, hipStream_t stream);
 void launchBsdfEvaluate(int64_t n, const double* in14, double* out4, hipStream_t stream);
 int traceBlocksPerCu();
+// Probe pass, two launches per camera: count survivors per pixel, then (with the
+// exclusive scan of the counts in `offsets`) write the records in pixel-major order.
+void launchGatherCount(const SceneView& scene, int32_t camera, int32_t stride, int64_t pixels, uint32_t* counts,
+                       unsigned long long* stats, hipStream_t stream);
+void launchGatherWrite(const SceneView& scene, int32_t camera, int32_t stride, int64_t pixels, const uint32_t* counts,
+                       const uint64_t* offsets, GatherPoint* out, hipStream_t stream);
+void launchProbeTest(const ProbeView& probes, int64_t n, const double* points, uint8_t* out, hipStream_t stream);
 
 }  // namespace rtd

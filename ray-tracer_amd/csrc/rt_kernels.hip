@@ -694,6 +694,67 @@ __global__ void bsdfEvaluateKernel(int64_t n, const double* in, double* out)
     o[3] = pdfMaterial(m, wi, wo, nn);
 }
 
+
+// ---------------------------------------------------------------- probe pass kernels
+// ProbeGather::collectGatherPoints (reference src/ProbeGather.cpp:239-460), one thread
+// per sampled pixel.  The reference walks pixels serially and appends records; here a
+// first launch counts each pixel's surviving samples and a second one, given the
+// exclusive scan of the counts, writes the records at their final positions — the same
+// pixel-major order, with no atomics.
+__global__ void gatherCountKernel(const SceneView s, int32_t camera, int32_t stride, uint32_t* counts,
+                                  unsigned long long* stats)
+{
+    const Camera& cam = s.cameras[camera];
+    const int32_t gw = (cam.width + stride - 1) / stride, gh = (cam.height + stride - 1) / stride;
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    unsigned long long local[3] = {0, 0, 0};
+    if (i < static_cast<int64_t>(gw) * gh)
+    {
+        const int32_t px = static_cast<int32_t>(i % gw) * stride, py = static_cast<int32_t>(i / gw) * stride;
+        counts[i] = static_cast<uint32_t>(collectPixel(s, camera, px, py, local, [](const GatherPoint&, int) {}));
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+    {
+        const unsigned long long total = waveSum(local[k]);
+        if ((threadIdx.x & 63) == 0 && total != 0)
+        {
+            atomicAdd(stats + k, total);
+        }
+    }
+}
+
+__global__ void gatherWriteKernel(const SceneView s, int32_t camera, int32_t stride, const uint32_t* counts,
+                                  const uint64_t* offsets, GatherPoint* out)
+{
+    const Camera& cam = s.cameras[camera];
+    const int32_t gw = (cam.width + stride - 1) / stride, gh = (cam.height + stride - 1) / stride;
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= static_cast<int64_t>(gw) * gh || counts[i] == 0)
+    {
+        return;
+    }
+    const int32_t px = static_cast<int32_t>(i % gw) * stride, py = static_cast<int32_t>(i / gw) * stride;
+    // sampleWeight = 1 / (surviving samples of the pixel), reference src/ProbeGather.cpp:445-456
+    const float weight = 1.0f / static_cast<float>(counts[i]);
+    GatherPoint* dst = out + offsets[i];
+    unsigned long long ignored[3] = {0, 0, 0};
+    collectPixel(s, camera, px, py, ignored, [&](const GatherPoint& gp, int k) {
+        GatherPoint w = gp;
+        w.sampleWeight = weight;
+        dst[k] = w;
+    });
+}
+
+// ProbeIndex::anyWithinKeepRadius for host-supplied points (emitter deposits,
+// reference src/ProbeGather.cpp:536-541).
+__global__ void probeTestKernel(const ProbeView pv, int64_t n, const double* points, uint8_t* out)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = anyProbeWithin(pv, mk(points[3 * i], points[3 * i + 1], points[3 * i + 2])) ? 1 : 0;
+}
+
 int gridFor(int64_t n) { return static_cast<int>((n + 255) / 256); }
 
 }  // namespace
@@ -739,6 +800,28 @@ void launchBsdfSample(int64_t n, const double* in14, double* out10, hipStream_t 
 {
     if (n <= 0) return;
     hipLaunchKernelGGL(bsdfSampleKernel, dim3(gridFor(n)), dim3(256), 0, stream, n, in14, out10);
+}
+
+void launchGatherCount(const SceneView& scene, int32_t camera, int32_t stride, int64_t pixels, uint32_t* counts,
+                       unsigned long long* stats, hipStream_t stream)
+{
+    if (pixels <= 0) return;
+    hipLaunchKernelGGL(gatherCountKernel, dim3(gridFor(pixels)), dim3(256), 0, stream, scene, camera, stride, counts,
+                       stats);
+}
+
+void launchGatherWrite(const SceneView& scene, int32_t camera, int32_t stride, int64_t pixels, const uint32_t* counts,
+                       const uint64_t* offsets, GatherPoint* out, hipStream_t stream)
+{
+    if (pixels <= 0) return;
+    hipLaunchKernelGGL(gatherWriteKernel, dim3(gridFor(pixels)), dim3(256), 0, stream, scene, camera, stride, counts,
+                       offsets, out);
+}
+
+void launchProbeTest(const ProbeView& probes, int64_t n, const double* points, uint8_t* out, hipStream_t stream)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(probeTestKernel, dim3(gridFor(n)), dim3(256), 0, stream, probes, n, points, out);
 }
 
 void launchBsdfEvaluate(int64_t n, const double* in14, double* out4, hipStream_t stream)

@@ -51,6 +51,9 @@ _SIGNATURES = {
                                     C.POINTER(C.c_uint64)]),
     "rt_read_records": (C.c_int32, [C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p]),
+    "rt_collect_gather_points": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64),
+                                             C.c_void_p]),
+    "rt_probe_keep_test": (C.c_int32, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "rt_cast_rays": (C.c_int32, [C.c_void_p, C.c_int64, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]),
     "rt_emit": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
     "rt_intersect_triangles": (C.c_int32, [C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]),
@@ -211,6 +214,37 @@ class Tracer:
                                                 _ptr(out["casts_valid"]), _ptr(out["bounce_f64"]),
                                                 _ptr(out["bounce_i32"]), _ptr(out["bounce_power"])))
         return out
+
+    # -- the probe pass -----------------------------------------------------
+    def collect_gather_points(self, camera=0):
+        """(rows[n, 19], stats) of one camera's probe pass; see rt_collect_gather_points."""
+        n = C.c_uint64()
+        stats = np.zeros(3, dtype=np.uint64)
+        _check(tracer_lib().rt_collect_gather_points(self._handle, camera, None, 0, C.byref(n), _ptr(stats)))
+        out = np.zeros((int(n.value), 19))
+        if n.value:
+            _check(tracer_lib().rt_collect_gather_points(self._handle, camera, _ptr(out), n.value, C.byref(n),
+                                                         _ptr(stats)))
+        names = ("camera_rays", "delta_extensions", "misses")
+        return out, dict(zip(names, (int(v) for v in stats)))
+
+    def collect_probe_positions(self):
+        """Gather-point positions of every camera, in camera order (what the reference's
+        Renderer feeds into ProbeIndex, src/Renderer.cpp:101-131)."""
+        desc = self.scene.desc
+        parts = [np.zeros((0, 3))]
+        for c in range(len(self.cameras)):
+            # debug cameras (bounce / light filter) run no gather and contribute no probes
+            if desc.cameras[c].bounce_filter >= 0 or desc.cameras[c].light_filter >= 0:
+                continue
+            parts.append(self.collect_gather_points(c)[0][:, 2:5])
+        return np.ascontiguousarray(np.concatenate(parts, axis=0))
+
+    def probe_keep_test(self, points):
+        points = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
+        keep = np.zeros(points.shape[0], dtype=np.uint8)
+        _check(tracer_lib().rt_probe_keep_test(self._handle, points.shape[0], _ptr(points), _ptr(keep)))
+        return keep.astype(bool)
 
     # -- function-level -----------------------------------------------------
     def cast_rays(self, rays, self_hit=1e-4):

@@ -51,9 +51,16 @@ def open_scene(rt, entry):
         s.photons_per_light = entry["photons_per_light"]
     if "fetch_size" in entry:
         s.fetch_size = entry["fetch_size"]
-    for key in ("use_probe_gather", "bounce_threshold", "seed", "seeded", "deterministic"):
+    if "seed" in entry and "seeded" not in entry:
+        s.seeded = 1
+    for key in ("use_probe_gather", "bounce_threshold", "seed", "seeded", "deterministic", "probe_sub_sample",
+                "camera_time_samples", "shutter_time", "frame_time"):
         if key in entry:
             setattr(s, key, entry[key])
+    if "image" in entry:  # every camera shrunk to image x image pixels
+        s.image_width = s.image_height = entry["image"]
+        for c in range(scene.desc.camera_count):
+            scene.desc.cameras[c].width = scene.desc.cameras[c].height = entry["image"]
     return scene
 
 

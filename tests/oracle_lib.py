@@ -119,6 +119,25 @@ class Oracle:
         lib().orc_emit_mt(self.ctx, light, n, seed, total_photons, _ptr(rays), _ptr(colors))
         return rays, colors
 
+    def collect_gather_points(self, camera=0, rng_mode=RNG_COUNTER, math_mode=MATH_PORTABLE):
+        """(rows[n, 19], stats) of the probe pass restatement (ProbeGather::collectGatherPoints)."""
+        rows = C.POINTER(C.c_double)()
+        n = lib().orc_collect_gather_points(self.ctx, camera, rng_mode, math_mode, C.byref(rows))
+        if n < 0:
+            raise RuntimeError("camera index out of range")
+        flat = np.ctypeslib.as_array(rows, shape=(n * 19 + 3,)).copy()
+        stats = dict(zip(("camera_rays", "delta_extensions", "misses"), (int(v) for v in flat[n * 19:])))
+        return flat[:n * 19].reshape(n, 19), stats
+
+    def collect_probe_positions(self, rng_mode=RNG_COUNTER, math_mode=MATH_PORTABLE):
+        desc = self.scene.desc
+        parts = [np.zeros((0, 3))]
+        for c in range(desc.camera_count):
+            if desc.cameras[c].bounce_filter >= 0 or desc.cameras[c].light_filter >= 0:
+                continue
+            parts.append(self.collect_gather_points(c, rng_mode, math_mode)[0][:, 2:5])
+        return np.ascontiguousarray(np.concatenate(parts, axis=0))
+
     def trace(self, rng_mode=RNG_COUNTER, math_mode=MATH_PORTABLE, sink_mode=SINK_NONE, threads=1,
               first_photon=0, photon_count=0, record_photons=0, probes=None, probe_cell_size=0.0,
               keep_radius=0.0, store_capacity=0, min_splat_radius=0.0, density_cell_size=0.0):

@@ -179,6 +179,63 @@ def test_probe_sink_store_equals_oracle(rt, scene_opener, name):
     assert c["store_size"] == small and c["store_dropped"] == ref["kept"] - small and c["store_attempted"] == ref["kept"]
 
 
+PROBE_SCENES = {
+    "mixed": {"scene": "tests/scenes/mixed.json"},
+    "bombardment": {"scene": "scenes/MirrorBombardment-200M.json", "image": 160, "seed": 11},
+    "cbgmd": {"scene": "scenes/CornellBoxGlassMirrorDiffuse.json", "image": 128, "probe_sub_sample": 2, "seed": 3},
+    "multicam": {"scene": "scenes/MultiCameraTest.json", "image": 96, "seed": 5},
+    "shutter": {"scene": "tests/scenes/mixed.json", "shutter_time": 0.25, "camera_time_samples": 4},
+}
+
+
+@pytest.mark.parametrize("name", sorted(PROBE_SCENES))
+def test_probe_pass_equals_oracle(rt, scene_opener, name):
+    """The device probe pass (one thread per pixel, count + write launches) returns the
+    oracle's gather points bit for bit, in the same pixel-major order, with the same counters."""
+    scene, tracer, orc = _open(rt, scene_opener, PROBE_SCENES[name])
+    total = 0
+    for c in range(scene.desc.camera_count):
+        got, stats = tracer.collect_gather_points(c)
+        want, ostats = orc.collect_gather_points(c, rng_mode=O.RNG_COUNTER, math_mode=O.MATH_PORTABLE)
+        assert stats == ostats
+        assert_bits_equal(got, want, f"{name} camera {c}")
+        total += got.shape[0]
+    assert total > 0
+    assert_bits_equal(tracer.collect_probe_positions(), orc.collect_probe_positions(), "probe union")
+
+
+def test_probe_pass_equals_reference_where_rng_free(rt, golden, manifest, scene_opener):
+    """Pixels that draw no random numbers (no glass, no lens, no shutter) must equal the
+    REFERENCE's records bit for bit; on the bombardment scene that is every pixel whose
+    first hit is not the glass sphere."""
+    g = golden("probes_bombardment")
+    scene, tracer, _ = _open(rt, scene_opener, manifest["probes_bombardment"])
+    got, stats = tracer.collect_gather_points(0)
+    want = g["probes_c0"]
+    assert stats["camera_rays"] == int(g["probes_counts_c0"][0])
+    direct_got, direct_want = got[got[:, 18] == 1.0], want[want[:, 18] == 1.0]
+    assert direct_want.shape[0] > 400
+    # sin/cos/acos play no part in pinhole rays or hits: libm vs portable math is moot here
+    assert_bits_equal(direct_got, direct_want, "RNG-free gather points vs reference")
+
+
+def test_probe_keep_test_matches_store_decisions(rt, scene_opener):
+    """rt_probe_keep_test gives, for points handed over from the host, the same decision the
+    photon pass takes for its own deposits."""
+    scene, tracer, orc = _open(rt, scene_opener, SCENES["mixed"])
+    pre = orc.trace(rng_mode=O.RNG_COUNTER, math_mode=O.MATH_PORTABLE, threads=8, record_photons=3000)
+    valid = pre["casts_valid"][:, 1] > 0
+    points = pre["bounce_f64"][:, 0, :3][valid]
+    probes = points[::7]
+    keep = 9.0
+    tracer.set_probes(probes, keep, keep, 1024)
+    got = tracer.probe_keep_test(points)
+    d2 = ((points[:, None, :] - probes[None, :, :]) ** 2).sum(-1).min(1)
+    clear = np.abs(np.sqrt(d2) - keep) > 1e-9
+    assert np.array_equal(got[clear], (d2 <= keep * keep)[clear])
+    assert got[::7].all()
+
+
 @pytest.mark.parametrize("name", ["mixed", "multicam", "cbgmd"])
 def test_splat_sink_equals_oracle(rt, scene_opener, name):
     """Sink B: direct camera splat (+ density grid).  Buffers are float-atomic sums, so they
