@@ -197,6 +197,7 @@ void buildScene(rt_tracer* t, const rt_scene* scene)
         int64_t triBase;
     };
     std::vector<MeshSpan> spans;
+    int maxDepth = 1;
     for (int64_t m = 0; m < scene->mesh_count; ++m)
     {
         const rt_mesh& mesh = scene->meshes[m];
@@ -207,6 +208,7 @@ void buildScene(rt_tracer* t, const rt_scene* scene)
         const double* pos = scene->tri_pos + 9 * mesh.first_triangle;
         const double* nrm = scene->tri_nrm + 9 * mesh.first_triangle;
         rtbvh::FlatMesh flat = rtbvh::build(pos, mesh.triangle_count);
+        maxDepth = std::max(maxDepth, flat.depth);
         MeshSpan span;
         span.nodeBase = static_cast<int32_t>(nodes.size());
         span.nodeCount = static_cast<int32_t>(flat.nodes.size());
@@ -219,7 +221,7 @@ void buildScene(rt_tracer* t, const rt_scene* scene)
             n.skip = fn.skip;
             n.triStart = fn.triStart;
             n.triCount = fn.triCount;
-            n.pad = 0;
+            n.right = fn.right;
             nodes.push_back(n);
         }
         for (int32_t original : flat.order)
@@ -427,6 +429,8 @@ void buildScene(rt_tracer* t, const rt_scene* scene)
     view.windowStart = windowStart;
     view.windowEnd = windowEnd;
     view.hasCamera = scene->camera_count > 0 ? 1 : 0;
+    require(maxDepth <= 48, "mesh tree too deep for the traversal stack");
+    view.stackDepth = maxDepth + 1;
     view.patches = t->patches.ptr;
     view.patchCount = static_cast<int32_t>(patches.size());
     view.frameTime = start;
@@ -563,7 +567,7 @@ int32_t rt_create(const rt_scene* scene, int32_t device, rt_tracer** out)
         buildScene(t.get(), scene);
         hipDeviceProp_t prop{};
         check(hipGetDeviceProperties(&prop, device), "hipGetDeviceProperties");
-        t->blocks = prop.multiProcessorCount * rtd::traceBlocksPerCu();
+        t->blocks = prop.multiProcessorCount * rtd::traceBlocksPerCu(t->view);
         resetState(t.get());
         check(hipStreamSynchronize(t->stream), "hipStreamSynchronize");
         *out = t.release();

@@ -74,6 +74,7 @@ struct Builder
         FlatNode node{};
         node.triStart = static_cast<int32_t>(out.order.size());
         node.triCount = 0;
+        node.right = -1;
         if (!objects.empty())
         {
             triangleBounds(objects[0], node.bmin, node.bmax);
@@ -110,7 +111,11 @@ struct Builder
                 }
                 node.triCount = static_cast<int32_t>(middle.size());
                 if (!left.empty()) generate(left, (splitAxis + 1) % 3, depth + 1);
-                if (!right.empty()) generate(right, (splitAxis + 1) % 3, depth + 1);
+                if (!right.empty())
+                {
+                    node.right = static_cast<int32_t>(out.nodes.size());
+                    generate(right, (splitAxis + 1) % 3, depth + 1);
+                }
             }
         }
         node.skip = static_cast<int32_t>(out.nodes.size());

@@ -3,9 +3,10 @@
 // The tree is the reference's median-split structure with page size 1
 // (reference src/Tree.cpp:18-36,172-205,289-362; include/Mesh.h:15-19): nodes are
 // emitted in the order Tree::castRayIntoNode visits them (page, left subtree, right
-// subtree), each with the index of the node that follows its subtree, so the device
-// can walk the same sequence without a stack.  Triangles are re-ordered so that
-// every node's page is a contiguous run.
+// subtree), each with the index of the node that follows its subtree and of its
+// right child.  Triangles are re-ordered so that every node's page is a contiguous
+// run; a triangle's position in that order is its rank in the reference's visiting
+// order, which is what breaks ties between equally distant hits.
 #pragma once
 
 #include <cstdint>
@@ -21,7 +22,7 @@ struct FlatNode
     int32_t skip;
     int32_t triStart;
     int32_t triCount;
-    int32_t pad;
+    int32_t right;  // index of the right child, -1 when there is none; a left child, when present, is node + 1
 };
 
 struct FlatMesh

@@ -89,9 +89,10 @@ RT_DEV Color operator*(const Color& a, const Color& b) { return Color{a.r * b.r,
 RT_DEV float brightness(const Color& c) { return c.r + c.g + c.b; }
 
 // ------------------------------------------------------------------ flattened scene
-// One node of a mesh's tree, in the reference's visiting order (node page, left
+// One node of a mesh's tree, stored in the reference's visiting order (node page, left
 // subtree, right subtree — src/Tree.cpp:207-237).  `skip` is the index of the next
-// node in that order once this node's subtree is left out.
+// node in that order once this node's subtree is left out; the left child, when there
+// is one, is the next node, and `right` is the right child (-1: none).
 struct Node
 {
     double bmin[3];
@@ -99,7 +100,7 @@ struct Node
     int32_t skip;
     int32_t triStart;  // into the mesh's page-ordered triangle arrays
     int32_t triCount;
-    int32_t pad;
+    int32_t right;
 };
 static_assert(sizeof(Node) == 64, "Node must be one 64-byte line");
 
@@ -173,7 +174,8 @@ struct SceneView
     const Light* lights;
     Camera* cameras;
     const EmitterPatch* patches;
-    int32_t patchCount, pad0;
+    int32_t patchCount;
+    int32_t stackDepth;  // traversal stack entries per lane (deepest tree + 1)
     int32_t volumeCount, lightCount, cameraCount, bounceThreshold;
     double terminationThreshold;
     double splatLuminanceClamp;
@@ -290,42 +292,31 @@ RT_DEV RayPrep prepareRay(const Ray& ray)
 }
 
 // Slab test with the per-ray reciprocals hoisted; identical results to
-// rayIntersectsBounds (the reciprocal is the same correctly rounded quotient).
+// rayIntersectsBounds (the reciprocal is the same correctly rounded quotient).  The
+// reference leaves its loop at the first axis whose interval is empty; the interval
+// only ever shrinks, so testing it once after the last axis gives the same answer
+// without a branch per axis.
 RT_DEV bool slabTest(const Ray& ray, const RayPrep& p, const double* bmin, const double* bmax, double* entry)
 {
     double tmin = 0.0;
     double tmax = kMaxDouble;
+    bool inside = true;
 #pragma unroll
     for (int i = 0; i < 3; ++i)
     {
         const double origin = axisOf(ray.o, i);
-        if (p.parallel[i])
-        {
-            if (origin < bmin[i] || origin > bmax[i])
-            {
-                return false;
-            }
-        }
-        else
-        {
-            double t1 = (bmin[i] - origin) * p.ood[i];
-            double t2 = (bmax[i] - origin) * p.ood[i];
-            if (t1 > t2)
-            {
-                const double t = t1;
-                t1 = t2;
-                t2 = t;
-            }
-            tmin = dmax(tmin, t1);
-            tmax = dmin(tmax, t2);
-            if (tmin > tmax)
-            {
-                return false;
-            }
-        }
+        const double lo = bmin[i], hi = bmax[i];
+        const double t1 = (lo - origin) * p.ood[i];
+        const double t2 = (hi - origin) * p.ood[i];
+        const double tnear = t1 > t2 ? t2 : t1;
+        const double tfar = t1 > t2 ? t1 : t2;
+        const bool par = p.parallel[i];
+        inside = inside && !(par && (origin < lo || origin > hi));
+        tmin = par ? tmin : dmax(tmin, tnear);
+        tmax = par ? tmax : dmin(tmax, tfar);
     }
     *entry = tmin;
-    return true;
+    return inside && !(tmin > tmax);
 }
 
 RT_DEV bool edgeAccept(double value, double ex, double ey)  // src/Ray.cpp:190-202
@@ -487,60 +478,150 @@ RT_DEV void quadUpdate(double* q)
 }
 
 // ------------------------------------------------------------------ scene cast
-// Closest hit of one mesh, equal to Tree::castRay's exhaustive minimum
-// (src/Tree.cpp:133-152,207-237): nodes are visited in the reference's order and a
-// candidate replaces the best only when strictly closer, so the first-found wins
-// exact ties as there.  A subtree is additionally skipped when the ray enters its
-// box farther than the best distance so far (with a 1e-9 relative margin for the
-// rounding between the box parameter and the reconstructed Euclidean distance):
-// such a subtree cannot hold a strictly closer hit, so the result is unchanged.
-RT_DEV bool castMesh(const SceneView& s, const Volume& vol, const Ray& ray, const RayPrep& prep, double* bary,
-                     Vec* position, double* distance, int32_t* triSlot)
+// Per-lane traversal stack in LDS: entry k of lane t lives at base[k * stride] so that
+// the 64 lanes of a wave always touch 64 different banks.  An entry packs the node
+// index (high word) and the ray parameter at which the ray enters the node's box,
+// rounded DOWN to a float (low word) — rounding down can only make pruning rarer.
+struct TraversalStack
 {
+    unsigned long long* base;
+    int32_t stride;
+};
+
+RT_DEV TraversalStack laneStack()
+{
+    extern __shared__ unsigned long long rtTraversalStack[];
+    return TraversalStack{rtTraversalStack + threadIdx.x, static_cast<int32_t>(blockDim.x)};
+}
+
+// Closest hit of one mesh, equal to Tree::castRay's exhaustive minimum
+// (src/Tree.cpp:133-152,207-237).  The reference visits every node whose box (and
+// whose ancestors' boxes) the ray meets, in page / left / right order, and keeps a
+// candidate only when it is strictly closer, so of equally distant hits the one
+// visited first wins.  The triangles are stored in that visiting order, so the same
+// winner is "smallest distance, then smallest slot" — which no longer depends on the
+// order of the walk.  That frees the walk to go near child first and to leave out any
+// subtree the ray enters beyond the best distance so far (or beyond `bound`, the
+// distance another volume has already achieved): such a subtree cannot hold a hit
+// that wins.  The comparison carries a margin far above the rounding of the box
+// parameter and of the reconstructed hit distance, so ties and near-ties are always
+// visited.  Triangle tests are deferred until every lane of the wave has either
+// reached a node with triangles or run out of nodes, so that the lanes test
+// triangles together instead of one lane at a time.
+RT_DEV bool castMesh(const SceneView& s, const Volume& vol, const Ray& ray, const RayPrep& prep,
+                     const TraversalStack& stack, double bound, double* bary, Vec* position, double* distance,
+                     int32_t* triSlot)
+{
+    if (vol.nodeCount <= 0)
+    {
+        return false;
+    }
     const Node* nodes = s.nodes + vol.nodeBase;
     const double* triPos = s.triPos + 9 * vol.triBase;
     const double dlen = magnitude(ray.d);
+    const Node& root = nodes[0];
+    double extent = 0.0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+    {
+        extent = dmax(extent, dmax(dabs(root.bmin[k]), dabs(root.bmax[k])));
+    }
+    const double slack = 1e-11 * (extent + dabs(ray.o.x) + dabs(ray.o.y) + dabs(ray.o.z));
     bool found = false;
     double best = kMaxDouble;
-    int32_t i = 0;
-    const int32_t count = vol.nodeCount;
-    while (i < count)
+    int32_t bestSlot = 0x7fffffff;
+    double cutoff = bound * (1.0 + 1e-9) + slack;  // kMaxDouble -> +inf: nothing is pruned
+
+    double rootEntry;
+    if (!slabTest(ray, prep, root.bmin, root.bmax, &rootEntry) || rootEntry * dlen > cutoff)
     {
-        const Node& node = nodes[i];
-        double entry;
-        bool descend = slabTest(ray, prep, node.bmin, node.bmax, &entry);
-        if (descend && found && entry * dlen > best * (1.0 + 1e-9))
+        return false;
+    }
+    int32_t cur = 0;
+    int32_t sp = 0;
+    bool tested = false;  // the triangles of `cur` were tested already
+    while (true)
+    {
+        int32_t pendingStart = 0, pendingEnd = 0;
+        while (cur >= 0)
         {
-            descend = false;
-        }
-        if (descend)
-        {
-            const int32_t t0 = node.triStart, t1 = t0 + node.triCount;
-            for (int32_t t = t0; t < t1; ++t)
+            const Node& node = nodes[cur];
+            const int32_t skip = node.skip, triStart = node.triStart, triCount = node.triCount, right = node.right;
+            if (triCount > 0 && !tested)
             {
-                double b3[3], d;
-                Vec pos;
-                if (rayIntersectsTriangle(ray, prep, triPos + 9 * t, b3, &pos, &d))
+                pendingStart = triStart;
+                pendingEnd = triStart + triCount;
+                break;
+            }
+            tested = false;
+            // children: the left one, if any, follows the node; both boxes are fetched
+            // and tested by every lane (absent children re-test the node itself)
+            const int32_t first = cur + 1;
+            const bool hasLeft = skip > first && right != first;
+            const bool hasRight = right >= 0;
+            const Node& ln = nodes[hasLeft ? first : cur];
+            const Node& rn = nodes[hasRight ? right : cur];
+            double el, er;
+            bool okl = slabTest(ray, prep, ln.bmin, ln.bmax, &el);
+            bool okr = slabTest(ray, prep, rn.bmin, rn.bmax, &er);
+            okl = okl && hasLeft && !(el * dlen > cutoff);
+            okr = okr && hasRight && !(er * dlen > cutoff);
+            if (okl && okr)
+            {
+                const bool leftNear = el <= er;
+                const int32_t farNode = leftNear ? right : first;
+                const float farEntry = __double2float_rd(leftNear ? er : el);
+                stack.base[sp * stack.stride] =
+                    (static_cast<unsigned long long>(static_cast<uint32_t>(farNode)) << 32) | __float_as_uint(farEntry);
+                sp += 1;
+                cur = leftNear ? first : right;
+            }
+            else if (okl || okr)
+            {
+                cur = okl ? first : right;
+            }
+            else
+            {
+                cur = -1;
+                while (sp > 0)
                 {
-                    if (!found || d < best)
+                    sp -= 1;
+                    const unsigned long long e = stack.base[sp * stack.stride];
+                    const double entry = static_cast<double>(__uint_as_float(static_cast<uint32_t>(e)));
+                    if (!(entry * dlen > cutoff))
                     {
-                        found = true;
-                        best = d;
-                        bary[0] = b3[0];
-                        bary[1] = b3[1];
-                        bary[2] = b3[2];
-                        *position = pos;
-                        *triSlot = t;
+                        cur = static_cast<int32_t>(e >> 32);
+                        break;
                     }
                 }
             }
-            i += 1;
         }
-        else
+        if (cur < 0)
         {
-            i = node.skip;
+            break;
         }
+        for (int32_t t = pendingStart; t < pendingEnd; ++t)
+        {
+            double b3[3], d;
+            Vec pos;
+            if (rayIntersectsTriangle(ray, prep, triPos + 9 * t, b3, &pos, &d))
+            {
+                if (!found || d < best || (d == best && t < bestSlot))
+                {
+                    found = true;
+                    best = d;
+                    bestSlot = t;
+                    bary[0] = b3[0];
+                    bary[1] = b3[1];
+                    bary[2] = b3[2];
+                    *position = pos;
+                    cutoff = dmin(best, bound) * (1.0 + 1e-9) + slack;
+                }
+            }
+        }
+        tested = true;
     }
+    *triSlot = bestSlot;
     *distance = best;
     return found;
 }
@@ -552,6 +633,7 @@ RT_DEV bool castMesh(const SceneView& s, const Volume& vol, const Ray& ray, cons
 // produced (occlusion test, src/Worker.cpp:314-333).
 RT_DEV bool castScene(const SceneView& s, const Ray& ray, double selfHit, bool needSurface, Hit* out)
 {
+    const TraversalStack stack = laneStack();
     double minDistance = kMaxDouble;
     bool valid = false;
     Vec bestPos = mk(0, 0, 0), bestNrm = mk(0, 0, 0);
@@ -572,7 +654,7 @@ RT_DEV bool castScene(const SceneView& s, const Ray& ray, double selfHit, bool n
             const RayPrep prep = prepareRay(local);
             double bary[3];
             int32_t slot = 0;
-            found = castMesh(s, vol, local, prep, bary, &pos, &dist, &slot);
+            found = castMesh(s, vol, local, prep, stack, minDistance, bary, &pos, &dist, &slot);
             if (found && dist < minDistance && dist > selfHit)
             {
                 if (needSurface)

@@ -521,7 +521,7 @@ __global__ __launch_bounds__(kTraceThreads) void traceKernel(const TraceArgs a)
 
 // ---------------------------------------------------------------- function-level kernels
 
-__global__ void castRaysKernel(const SceneView s, int64_t n, const double* rays, double selfHit, double* outF64,
+__global__ __launch_bounds__(256) void castRaysKernel(const SceneView s, int64_t n, const double* rays, double selfHit, double* outF64,
                                int32_t* outI32)
 {
     const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -701,7 +701,7 @@ __global__ void bsdfEvaluateKernel(int64_t n, const double* in, double* out)
 // first launch counts each pixel's surviving samples and a second one, given the
 // exclusive scan of the counts, writes the records at their final positions — the same
 // pixel-major order, with no atomics.
-__global__ void gatherCountKernel(const SceneView s, int32_t camera, int32_t stride, uint32_t* counts,
+__global__ __launch_bounds__(256) void gatherCountKernel(const SceneView s, int32_t camera, int32_t stride, uint32_t* counts,
                                   unsigned long long* stats)
 {
     const Camera& cam = s.cameras[camera];
@@ -724,7 +724,7 @@ __global__ void gatherCountKernel(const SceneView s, int32_t camera, int32_t str
     }
 }
 
-__global__ void gatherWriteKernel(const SceneView s, int32_t camera, int32_t stride, const uint32_t* counts,
+__global__ __launch_bounds__(256) void gatherWriteKernel(const SceneView s, int32_t camera, int32_t stride, const uint32_t* counts,
                                   const uint64_t* offsets, GatherPoint* out)
 {
     const Camera& cam = s.cameras[camera];
@@ -757,18 +757,27 @@ __global__ void probeTestKernel(const ProbeView pv, int64_t n, const double* poi
 
 int gridFor(int64_t n) { return static_cast<int>((n + 255) / 256); }
 
+// dynamic LDS of a kernel that casts rays: one traversal stack per lane
+size_t stackBytes(const SceneView& scene, int threads)
+{
+    return static_cast<size_t>(scene.stackDepth > 0 ? scene.stackDepth : 1) * static_cast<size_t>(threads) *
+           sizeof(unsigned long long);
+}
+
 }  // namespace
 
 void launchTrace(const TraceArgs& args, int blocks, int threads, hipStream_t stream)
 {
     (void)threads;
-    hipLaunchKernelGGL(traceKernel, dim3(blocks), dim3(kTraceThreads), 0, stream, args);
+    hipLaunchKernelGGL(traceKernel, dim3(blocks), dim3(kTraceThreads), stackBytes(args.scene, kTraceThreads), stream, args);
 }
 
-int traceBlocksPerCu()
+int traceBlocksPerCu(const SceneView& scene)
 {
     int blocks = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, traceKernel, kTraceThreads, 0) != hipSuccess || blocks < 1)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, traceKernel, kTraceThreads,
+                                                     stackBytes(scene, kTraceThreads)) != hipSuccess ||
+        blocks < 1)
     {
         blocks = 2;
     }
@@ -779,7 +788,7 @@ void launchCastRays(const SceneView& scene, int64_t n, const double* rays, doubl
                     int32_t* outI32, hipStream_t stream)
 {
     if (n <= 0) return;
-    hipLaunchKernelGGL(castRaysKernel, dim3(gridFor(n)), dim3(256), 0, stream, scene, n, rays, selfHit, outF64, outI32);
+    hipLaunchKernelGGL(castRaysKernel, dim3(gridFor(n)), dim3(256), stackBytes(scene, 256), stream, scene, n, rays, selfHit, outF64, outI32);
 }
 
 void launchEmit(const SceneView& scene, int32_t light, int64_t n, const double* draws5, uint64_t totalPhotons,
@@ -806,7 +815,7 @@ void launchGatherCount(const SceneView& scene, int32_t camera, int32_t stride, i
                        unsigned long long* stats, hipStream_t stream)
 {
     if (pixels <= 0) return;
-    hipLaunchKernelGGL(gatherCountKernel, dim3(gridFor(pixels)), dim3(256), 0, stream, scene, camera, stride, counts,
+    hipLaunchKernelGGL(gatherCountKernel, dim3(gridFor(pixels)), dim3(256), stackBytes(scene, 256), stream, scene, camera, stride, counts,
                        stats);
 }
 
@@ -814,7 +823,7 @@ void launchGatherWrite(const SceneView& scene, int32_t camera, int32_t stride, i
                        const uint64_t* offsets, GatherPoint* out, hipStream_t stream)
 {
     if (pixels <= 0) return;
-    hipLaunchKernelGGL(gatherWriteKernel, dim3(gridFor(pixels)), dim3(256), 0, stream, scene, camera, stride, counts,
+    hipLaunchKernelGGL(gatherWriteKernel, dim3(gridFor(pixels)), dim3(256), stackBytes(scene, 256), stream, scene, camera, stride, counts,
                        offsets, out);
 }
 
