@@ -13,6 +13,7 @@
 #include <limits>
 #include <map>
 #include <memory>
+#include <unordered_map>
 #include <stdexcept>
 #include <string>
 #include <tuple>
@@ -140,6 +141,8 @@ struct rt_tracer
     DeviceArray<int64_t> slotKey;
     DeviceArray<uint32_t> slotStart, slotCount;
     DeviceArray<double> probePoints;
+    DeviceArray<unsigned long long> nearKey;
+    DeviceArray<uint32_t> nearBits;
     rtd::ProbeView probeView{};
     DeviceArray<float> storeRecords;
     uint64_t storeCapacity = 0;
@@ -653,6 +656,68 @@ int32_t rt_set_probes(rt_tracer* tracer, const double* probes, uint64_t n, doubl
         pv.keepRadius = keepRadius;
         pv.reach = static_cast<int64_t>(std::ceil(keepRadius * invCellSize));
         require(pv.reach <= 64, "keep radius spans too many probe cells");
+
+        // neighbourhood filter: which cells have an occupied cell among their 27 neighbours
+        pv.nearKey = nullptr;
+        pv.nearBits = nullptr;
+        pv.nearMask = 0;
+        tracer->nearKey.release();
+        tracer->nearBits.release();
+        const int64_t lim = (1 << 20) - 2;
+        bool packable = pv.reach == 1 && !cells.empty();
+        for (const auto& cell : cells)
+        {
+            const CellKey& k = cell.first;
+            packable = packable && k.x > -lim && k.x < lim && k.y > -lim && k.y < lim && k.z > -lim && k.z < lim;
+        }
+        if (packable)
+        {
+            std::unordered_map<unsigned long long, uint32_t> near;
+            near.reserve(cells.size() * 8);
+            auto pack = [](int64_t x, int64_t y, int64_t z) {
+                const int64_t off = 1 << 20;
+                return (static_cast<unsigned long long>(x + off) << 42) | (static_cast<unsigned long long>(y + off) << 21) |
+                       static_cast<unsigned long long>(z + off);
+            };
+            for (const auto& cell : cells)
+            {
+                const CellKey& k = cell.first;
+                for (int dz = -1; dz <= 1; ++dz)
+                    for (int dy = -1; dy <= 1; ++dy)
+                        for (int dx = -1; dx <= 1; ++dx)
+                        {
+                            // the occupied cell k is the neighbour at (-dx, -dy, -dz) of the cell k + d
+                            const int bit = (1 - dz) * 9 + (1 - dy) * 3 + (1 - dx);
+                            near[pack(k.x + dx, k.y + dy, k.z + dz)] |= 1u << bit;
+                        }
+            }
+            uint64_t nearSlots = 16;
+            while (nearSlots < 2 * near.size() + 1)
+            {
+                nearSlots <<= 1;
+            }
+            std::vector<unsigned long long> nearKey(nearSlots, rtd::kEmptyKey);
+            std::vector<uint32_t> nearBits(nearSlots, 0);
+            const unsigned long long field = (1ull << 21) - 1;
+            for (const auto& entry : near)
+            {
+                const CellKey k{static_cast<int64_t>(entry.first >> 42) - (1 << 20),
+                                static_cast<int64_t>((entry.first >> 21) & field) - (1 << 20),
+                                static_cast<int64_t>(entry.first & field) - (1 << 20)};
+                uint64_t slot = cellSlot(k, nearSlots - 1);
+                while (nearKey[slot] != rtd::kEmptyKey)
+                {
+                    slot = (slot + 1) & (nearSlots - 1);
+                }
+                nearKey[slot] = entry.first;
+                nearBits[slot] = entry.second;
+            }
+            tracer->nearKey.upload(nearKey);
+            tracer->nearBits.upload(nearBits);
+            pv.nearKey = tracer->nearKey.ptr;
+            pv.nearBits = tracer->nearBits.ptr;
+            pv.nearMask = nearSlots - 1;
+        }
         tracer->storeCapacity = store_capacity;
         tracer->storeRecords.allocate(static_cast<size_t>(store_capacity) * 13);
         tracer->probesSet = true;

@@ -20,6 +20,12 @@ struct ProbeView
     double invCellSize;
     double keepRadius;
     int64_t reach;               // ceil(keepRadius * invCellSize)
+    // Neighbourhood filter (only when reach == 1 and every probe cell packs into 3 x 21
+    // bits; nearMask == 0 otherwise): every cell that has an occupied cell among its 27
+    // neighbours, with one bit per occupied neighbour, bit (dz+1)*9 + (dy+1)*3 + (dx+1).
+    const unsigned long long* nearKey;  // [nearMask + 1] packed cell, kEmptyKey when free
+    const uint32_t* nearBits;           // [nearMask + 1]
+    uint64_t nearMask;
 };
 
 struct StoreView

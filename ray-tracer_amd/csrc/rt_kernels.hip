@@ -49,9 +49,49 @@ RT_DEV double waveSumD(double v)
     return v;
 }
 
+constexpr int64_t kPackLimit = 1 << 20;  // packed cell coordinates lie in [-2^20, 2^20)
+
+RT_DEV uint64_t cellHash(int64_t kx, int64_t ky, int64_t kz)  // reference include/ProbeIndex.h:71-80
+{
+    uint64_t h = static_cast<uint64_t>(kx) * 73856093ull;
+    h ^= static_cast<uint64_t>(ky) * 19349663ull;
+    h ^= static_cast<uint64_t>(kz) * 83492791ull;
+    return (h * 0x9E3779B97F4A7C15ull) >> 20;
+}
+
+// Is a probe of cell (kx, ky, kz) within the keep radius of p?
+RT_DEV bool probeCellHas(const ProbeView& pv, int64_t kx, int64_t ky, int64_t kz, const Vec& p, double r2)
+{
+    uint64_t slot = cellHash(kx, ky, kz) & pv.slotMask;
+    while (true)
+    {
+        const uint32_t count = pv.slotCount[slot];
+        if (count == 0)
+        {
+            return false;
+        }
+        const int64_t* key = pv.slotKey + 3 * slot;
+        if (key[0] == kx && key[1] == ky && key[2] == kz)
+        {
+            const double* pt = pv.points + 3ull * pv.slotStart[slot];
+            for (uint32_t i = 0; i < count; ++i)
+            {
+                const double ddx = pt[3 * i] - p.x, ddy = pt[3 * i + 1] - p.y, ddz = pt[3 * i + 2] - p.z;
+                if (ddx * ddx + ddy * ddy + ddz * ddz <= r2)
+                {
+                    return true;
+                }
+            }
+            return false;
+        }
+        slot = (slot + 1) & pv.slotMask;
+    }
+}
+
 // ProbeIndex::anyWithin, reference src/ProbeIndex.cpp:27-68.  The result is a pure
 // "exists", so the scan order is free; the squared-distance test is the reference's
-// expression.
+// expression.  With the neighbourhood filter one lookup tells which of the 27 cells
+// around p hold probes at all: a deposit far from every probe costs that one lookup.
 RT_DEV bool anyProbeWithin(const ProbeView& pv, const Vec& p)
 {
     const double r = pv.keepRadius;
@@ -63,6 +103,46 @@ RT_DEV bool anyProbeWithin(const ProbeView& pv, const Vec& p)
     const int64_t cx = static_cast<int64_t>(__builtin_floor(p.x * pv.invCellSize));
     const int64_t cy = static_cast<int64_t>(__builtin_floor(p.y * pv.invCellSize));
     const int64_t cz = static_cast<int64_t>(__builtin_floor(p.z * pv.invCellSize));
+    if (pv.nearMask != 0)
+    {
+        // probe cells lie strictly inside the packable range, so a cell on or beyond
+        // its border has no occupied neighbour
+        if (cx <= -kPackLimit || cx >= kPackLimit - 1 || cy <= -kPackLimit || cy >= kPackLimit - 1 ||
+            cz <= -kPackLimit || cz >= kPackLimit - 1)
+        {
+            return false;
+        }
+        const unsigned long long key = (static_cast<unsigned long long>(cx + kPackLimit) << 42) |
+                                       (static_cast<unsigned long long>(cy + kPackLimit) << 21) |
+                                       static_cast<unsigned long long>(cz + kPackLimit);
+        uint64_t slot = cellHash(cx, cy, cz) & pv.nearMask;
+        uint32_t bits = 0;
+        while (true)
+        {
+            const unsigned long long seen = pv.nearKey[slot];
+            if (seen == key)
+            {
+                bits = pv.nearBits[slot];
+                break;
+            }
+            if (seen == kEmptyKey)
+            {
+                break;
+            }
+            slot = (slot + 1) & pv.nearMask;
+        }
+        while (bits != 0)
+        {
+            const int b = __builtin_ctz(bits);
+            bits &= bits - 1;
+            const int dz = b / 9 - 1, dy = (b / 3) % 3 - 1, dx = b % 3 - 1;
+            if (probeCellHas(pv, cx + dx, cy + dy, cz + dz, p, r2))
+            {
+                return true;
+            }
+        }
+        return false;
+    }
     const int64_t reach = pv.reach;
     for (int64_t dz = -reach; dz <= reach; ++dz)
     {
@@ -70,33 +150,9 @@ RT_DEV bool anyProbeWithin(const ProbeView& pv, const Vec& p)
         {
             for (int64_t dx = -reach; dx <= reach; ++dx)
             {
-                const int64_t kx = cx + dx, ky = cy + dy, kz = cz + dz;
-                uint64_t h = static_cast<uint64_t>(kx) * 73856093ull;
-                h ^= static_cast<uint64_t>(ky) * 19349663ull;
-                h ^= static_cast<uint64_t>(kz) * 83492791ull;
-                uint64_t slot = (h * 0x9E3779B97F4A7C15ull) >> 20 & pv.slotMask;
-                while (true)
+                if (probeCellHas(pv, cx + dx, cy + dy, cz + dz, p, r2))
                 {
-                    const uint32_t count = pv.slotCount[slot];
-                    if (count == 0)
-                    {
-                        break;
-                    }
-                    const int64_t* key = pv.slotKey + 3 * slot;
-                    if (key[0] == kx && key[1] == ky && key[2] == kz)
-                    {
-                        const double* pt = pv.points + 3ull * pv.slotStart[slot];
-                        for (uint32_t i = 0; i < count; ++i)
-                        {
-                            const double ddx = pt[3 * i] - p.x, ddy = pt[3 * i + 1] - p.y, ddz = pt[3 * i + 2] - p.z;
-                            if (ddx * ddx + ddy * ddy + ddz * ddz <= r2)
-                            {
-                                return true;
-                            }
-                        }
-                        break;
-                    }
-                    slot = (slot + 1) & pv.slotMask;
+                    return true;
                 }
             }
         }

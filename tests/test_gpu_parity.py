@@ -234,6 +234,9 @@ def test_probe_keep_test_matches_store_decisions(rt, scene_opener):
     clear = np.abs(np.sqrt(d2) - keep) > 1e-9
     assert np.array_equal(got[clear], (d2 <= keep * keep)[clear])
     assert got[::7].all()
+    # a cell size below the keep radius (reach 2) takes the unfiltered scan
+    tracer.set_probes(probes, 5.0, keep, 1024)
+    assert np.array_equal(tracer.probe_keep_test(points), got)
 
 
 @pytest.mark.parametrize("name", ["mixed", "multicam", "cbgmd"])
