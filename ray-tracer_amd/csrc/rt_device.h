@@ -245,10 +245,19 @@ RT_DEV bool rayIntersectsBounds(const Ray& ray, const double* bmin, const double
 // Per-ray constants of the slab and watertight tests (they depend on the ray only).
 struct RayPrep
 {
-    double ood[3];       // 1 / direction per axis (unused where parallel[i])
-    bool parallel[3];    // |direction| < epsilon
+    // Slab test.  A box is six doubles (min xyz, max xyz); nearIdx[i] / farIdx[i] pick the
+    // plane of axis i the ray meets first / last, which is what the reference's
+    // "swap when t1 > t2" amounts to: the order of the two products follows the sign of
+    // the reciprocal.  ood is 1 / direction, or +infinity on an axis the reference
+    // treats as parallel (|direction| < epsilon): there (plane - origin) * inf is -inf /
+    // +inf while the origin lies between the planes (or NaN on a plane, which the
+    // IEEE max / min below ignore) and drives the interval empty when it lies outside,
+    // exactly the reference's containment test (src/Ray.cpp:24-32).
+    double ood[3];
+    int32_t nearIdx[3], farIdx[3];
     int kx, ky, kz;      // watertight axis permutation, src/Ray.cpp:100-139
     double sx, sy, sz;   // shear constants, :141-147
+    double okx, oky, okz;  // ray origin in permuted order
 };
 
 RT_DEV RayPrep prepareRay(const Ray& ray)
@@ -258,8 +267,12 @@ RT_DEV RayPrep prepareRay(const Ray& ray)
     for (int i = 0; i < 3; ++i)
     {
         const double d = axisOf(ray.d, i);
-        p.parallel[i] = dabs(d) < kEps;
-        p.ood[i] = 1.0 / d;
+        const bool parallel = dabs(d) < kEps;
+        const double ood = 1.0 / d;
+        p.ood[i] = parallel ? __builtin_inf() : ood;
+        const bool reversed = !parallel && ood < 0.0;
+        p.nearIdx[i] = reversed ? i + 3 : i;
+        p.farIdx[i] = reversed ? i : i + 3;
     }
     const double adx = dabs(ray.d.x), ady = dabs(ray.d.y), adz = dabs(ray.d.z);
     int kz = 2;
@@ -288,35 +301,31 @@ RT_DEV RayPrep prepareRay(const Ray& ray)
     p.sx = dkx / dkz;
     p.sy = dky / dkz;
     p.sz = 1.0 / dkz;
+    p.okx = axisOf(ray.o, kx);
+    p.oky = axisOf(ray.o, ky);
+    p.okz = axisOf(ray.o, kz);
     return p;
 }
 
-// Slab test with the per-ray reciprocals hoisted; identical results to
-// rayIntersectsBounds (the reciprocal is the same correctly rounded quotient).  The
-// reference leaves its loop at the first axis whose interval is empty; the interval
-// only ever shrinks, so testing it once after the last axis gives the same answer
-// without a branch per axis.
-RT_DEV bool slabTest(const Ray& ray, const RayPrep& p, const double* bmin, const double* bmax, double* entry)
+// Slab test with the per-ray constants hoisted; same decision and same entry parameter
+// as rayIntersectsBounds.  The reference leaves its loop at the first axis whose
+// interval is empty; the interval only ever shrinks, so testing it once after the last
+// axis gives the same answer.  `box` points at six doubles in memory (min xyz, max xyz).
+RT_DEV bool slabTest(const Ray& ray, const RayPrep& p, const double* box, double* entry)
 {
     double tmin = 0.0;
     double tmax = kMaxDouble;
-    bool inside = true;
 #pragma unroll
     for (int i = 0; i < 3; ++i)
     {
         const double origin = axisOf(ray.o, i);
-        const double lo = bmin[i], hi = bmax[i];
-        const double t1 = (lo - origin) * p.ood[i];
-        const double t2 = (hi - origin) * p.ood[i];
-        const double tnear = t1 > t2 ? t2 : t1;
-        const double tfar = t1 > t2 ? t1 : t2;
-        const bool par = p.parallel[i];
-        inside = inside && !(par && (origin < lo || origin > hi));
-        tmin = par ? tmin : dmax(tmin, tnear);
-        tmax = par ? tmax : dmin(tmax, tfar);
+        const double tnear = (box[p.nearIdx[i]] - origin) * p.ood[i];
+        const double tfar = (box[p.farIdx[i]] - origin) * p.ood[i];
+        tmin = __builtin_fmax(tmin, tnear);
+        tmax = __builtin_fmin(tmax, tfar);
     }
     *entry = tmin;
-    return inside && !(tmin > tmax);
+    return !(tmin > tmax);
 }
 
 RT_DEV bool edgeAccept(double value, double ex, double ey)  // src/Ray.cpp:190-202
@@ -327,16 +336,16 @@ RT_DEV bool edgeAccept(double value, double ex, double ey)  // src/Ray.cpp:190-2
 }
 
 // Watertight ray/triangle test, src/Ray.cpp:85-247.  On a hit writes the barycentric
-// weights, the reconstructed position and the Euclidean distance.
+// weights, the reconstructed position and the Euclidean distance.  `tp` points at the
+// nine vertex coordinates in memory; the sheared coordinates need the vertices in the
+// ray's permuted axis order, which is read straight from memory by index.
 RT_DEV bool rayIntersectsTriangle(const Ray& ray, const RayPrep& p, const double* tp, double* bary, Vec* position,
                                   double* distance)
 {
-    const Vec a = mk(tp[0], tp[1], tp[2]), b = mk(tp[3], tp[4], tp[5]), c = mk(tp[6], tp[7], tp[8]);
-    const Vec vA = a - ray.o, vB = b - ray.o, vC = c - ray.o;
-    const double aKz = axisOf(vA, p.kz), bKz = axisOf(vB, p.kz), cKz = axisOf(vC, p.kz);
-    const double ax = axisOf(vA, p.kx) - p.sx * aKz, ay = axisOf(vA, p.ky) - p.sy * aKz;
-    const double bx = axisOf(vB, p.kx) - p.sx * bKz, by = axisOf(vB, p.ky) - p.sy * bKz;
-    const double cx = axisOf(vC, p.kx) - p.sx * cKz, cy = axisOf(vC, p.ky) - p.sy * cKz;
+    const double aKz = tp[p.kz] - p.okz, bKz = tp[3 + p.kz] - p.okz, cKz = tp[6 + p.kz] - p.okz;
+    const double ax = (tp[p.kx] - p.okx) - p.sx * aKz, ay = (tp[p.ky] - p.oky) - p.sy * aKz;
+    const double bx = (tp[3 + p.kx] - p.okx) - p.sx * bKz, by = (tp[3 + p.ky] - p.oky) - p.sy * bKz;
+    const double cx = (tp[6 + p.kx] - p.okx) - p.sx * cKz, cy = (tp[6 + p.ky] - p.oky) - p.sy * cKz;
 
     const double u = cx * by - cy * bx;
     const double v = ax * cy - ay * cx;
@@ -357,6 +366,7 @@ RT_DEV bool rayIntersectsTriangle(const Ray& ray, const RayPrep& p, const double
     {
         return false;
     }
+    const Vec a = mk(tp[0], tp[1], tp[2]), b = mk(tp[3], tp[4], tp[5]), c = mk(tp[6], tp[7], tp[8]);
     const double invDet = 1.0 / det;
     const double ca = u * invDet, cb = v * invDet, cc = w * invDet;
     const Vec pos = (ca * a) + (cb * b) + (cc * c);  // src/Triangle.cpp:42-45
@@ -533,7 +543,7 @@ RT_DEV bool castMesh(const SceneView& s, const Volume& vol, const Ray& ray, cons
     double cutoff = bound * (1.0 + 1e-9) + slack;  // kMaxDouble -> +inf: nothing is pruned
 
     double rootEntry;
-    if (!slabTest(ray, prep, root.bmin, root.bmax, &rootEntry) || rootEntry * dlen > cutoff)
+    if (!slabTest(ray, prep, root.bmin, &rootEntry) || rootEntry * dlen > cutoff)
     {
         return false;
     }
@@ -562,8 +572,8 @@ RT_DEV bool castMesh(const SceneView& s, const Volume& vol, const Ray& ray, cons
             const Node& ln = nodes[hasLeft ? first : cur];
             const Node& rn = nodes[hasRight ? right : cur];
             double el, er;
-            bool okl = slabTest(ray, prep, ln.bmin, ln.bmax, &el);
-            bool okr = slabTest(ray, prep, rn.bmin, rn.bmax, &er);
+            bool okl = slabTest(ray, prep, ln.bmin, &el);
+            bool okr = slabTest(ray, prep, rn.bmin, &er);
             okl = okl && hasLeft && !(el * dlen > cutoff);
             okr = okr && hasRight && !(er * dlen > cutoff);
             if (okl && okr)

@@ -662,7 +662,15 @@ __global__ void intersectKernel(int kind, int64_t n, const double* in, void* out
         }
         const bool direct = rayIntersectsBounds(ray, lo, hi, &entry);
         const RayPrep prep = prepareRay(ray);
-        const bool hoisted = slabTest(ray, prep, lo, hi, &entry);
+        // the hoisted test reads its box from memory: stage the sorted corners after the
+        // row's own output slot is known to be free (rows are 12 doubles, the box is 6)
+        double* box = const_cast<double*>(r) + 6;
+        for (int k = 0; k < 3; ++k)
+        {
+            box[k] = lo[k];
+            box[3 + k] = hi[k];
+        }
+        const bool hoisted = slabTest(ray, prep, box, &entry);
         // both forms must agree; report 2 if they ever do not
         static_cast<int32_t*>(outRaw)[i] = direct == hoisted ? (direct ? 1 : 0) : 2;
     }
