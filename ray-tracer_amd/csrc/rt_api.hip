@@ -583,6 +583,9 @@ void rt_destroy(rt_tracer* tracer)
     {
         (void)hipSetDevice(tracer->device);
         (void)hipDeviceSynchronize();
+#ifdef RT_DIAG
+        rtd::printDiagnostics();
+#endif
         delete tracer;
     }
 }

@@ -20,6 +20,24 @@
 
 #define RT_DEV __device__ __forceinline__
 
+// Optional divergence census (build with -DRT_DIAG): wave-level trip counts and active
+// lanes of the traversal loops, printed when a tracer is destroyed.
+#ifdef RT_DIAG
+__device__ unsigned long long g_rtDiag[16];
+#define RT_DIAG_TRIP(slot)                                                                     \
+    do                                                                                         \
+    {                                                                                          \
+        const unsigned long long diagMask = __ballot(1);                                       \
+        if (static_cast<int>(threadIdx.x & 63) == __builtin_ctzll(diagMask))                   \
+        {                                                                                      \
+            atomicAdd(&g_rtDiag[slot], 1ull);                                                  \
+            atomicAdd(&g_rtDiag[(slot) + 1], static_cast<unsigned long long>(__builtin_popcountll(diagMask))); \
+        }                                                                                      \
+    } while (0)
+#else
+#define RT_DIAG_TRIP(slot) do { } while (0)
+#endif
+
 namespace rtd
 {
 
@@ -526,6 +544,7 @@ RT_DEV bool castMesh(const SceneView& s, const Volume& vol, const Ray& ray, cons
     {
         return false;
     }
+    RT_DIAG_TRIP(0);  // mesh casts
     const Node* nodes = s.nodes + vol.nodeBase;
     const double* triPos = s.triPos + 9 * vol.triBase;
     const double dlen = magnitude(ray.d);
@@ -552,9 +571,11 @@ RT_DEV bool castMesh(const SceneView& s, const Volume& vol, const Ray& ray, cons
     bool tested = false;  // the triangles of `cur` were tested already
     while (true)
     {
+        RT_DIAG_TRIP(2);  // outer rounds
         int32_t pendingStart = 0, pendingEnd = 0;
         while (cur >= 0)
         {
+            RT_DIAG_TRIP(4);  // node steps
             const Node& node = nodes[cur];
             const int32_t skip = node.skip, triStart = node.triStart, triCount = node.triCount, right = node.right;
             if (triCount > 0 && !tested)
@@ -612,6 +633,7 @@ RT_DEV bool castMesh(const SceneView& s, const Volume& vol, const Ray& ray, cons
         }
         for (int32_t t = pendingStart; t < pendingEnd; ++t)
         {
+            RT_DIAG_TRIP(6);  // triangle tests
             double b3[3], d;
             Vec pos;
             if (rayIntersectsTriangle(ray, prep, triPos + 9 * t, b3, &pos, &d))

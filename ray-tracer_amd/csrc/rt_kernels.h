@@ -93,6 +93,9 @@ void launchIntersect(int kind, int64_t n, const double* in, void* out, hipStream
 void launchBsdfSample(int64_t n, const double* in14, double* out10, hipStream_t stream);
 void launchBsdfEvaluate(int64_t n, const double* in14, double* out4, hipStream_t stream);
 int traceBlocksPerCu(const SceneView& scene);
+#ifdef RT_DIAG
+void printDiagnostics();
+#endif
 // Probe pass, two launches per camera: count survivors per pixel, then (with the
 // exclusive scan of the counts in `offsets`) write the records in pixel-major order.
 void launchGatherCount(const SceneView& scene, int32_t camera, int32_t stride, int64_t pixels, uint32_t* counts,

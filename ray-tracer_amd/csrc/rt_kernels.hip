@@ -13,6 +13,8 @@
 
 #include "rt_kernels.h"
 
+#include <cstdio>
+
 namespace rtd
 {
 
@@ -333,6 +335,9 @@ RT_DEV void splatToCamera(const TraceArgs& a, const Vec& incoming, const Color& 
     }
 }
 
+// Sink selects the deposit path and Record the per-photon path dump at compile time, so
+// that the probe-sink kernel carries neither the splat's shadow-ray cast nor the dump.
+template <int Sink, bool Record>
 __global__ __launch_bounds__(kTraceThreads) void traceKernel(const TraceArgs a)
 {
     const SceneView& s = a.scene;
@@ -416,7 +421,7 @@ __global__ __launch_bounds__(kTraceThreads) void traceKernel(const TraceArgs a)
                             time = s.windowStart;
                         }
                     }
-                    recordSlot = id < a.records.recordPhotons ? static_cast<long long>(id) : -1;
+                    recordSlot = (Record && id < a.records.recordPhotons) ? static_cast<long long>(id) : -1;
                     if (recordSlot >= 0)
                     {
                         double* e = a.records.emitted + 6 * recordSlot;
@@ -441,6 +446,7 @@ __global__ __launch_bounds__(kTraceThreads) void traceKernel(const TraceArgs a)
         // ---- one bounce (Worker::processPhotons loop body, src/Worker.cpp:530-673) ----
         if (alive)
         {
+            RT_DIAG_TRIP(8);
             bool done = false;
             if (static_cast<double>(brightness(color)) < kEps)
             {
@@ -459,7 +465,7 @@ __global__ __launch_bounds__(kTraceThreads) void traceKernel(const TraceArgs a)
             {
                 const Material& material = s.materials[hit.material];
                 const bool delta = materialIsDelta(material.type);
-                if (recordSlot >= 0 && valid < a.records.maxBounces)
+                if (Record && recordSlot >= 0 && valid < a.records.maxBounces)
                 {
                     const long long slot = recordSlot * a.records.maxBounces + valid;
                     double* f = a.records.f64 + 10 * slot;
@@ -481,18 +487,19 @@ __global__ __launch_bounds__(kTraceThreads) void traceKernel(const TraceArgs a)
                     lc.power[1] += color.g;
                     lc.power[2] += color.b;
                 }
-                if (a.sinkMode == kSinkProbe)
+                if (Sink == kSinkProbe)
                 {
                     bool keep = false;
                     if (!delta)
                     {
+                        RT_DIAG_TRIP(10);
                         keep = anyProbeWithin(a.probes, hit.position);
                         if (keep) lc.kept += 1;
                         else lc.culled += 1;
                     }
                     storeAppend(a.store, keep, hit.position, ray.d, hit.normal, time, color);
                 }
-                else if (a.sinkMode == kSinkSplat)
+                else if (Sink == kSinkSplat)
                 {
                     if (a.density.enabled && !delta)
                     {
@@ -537,7 +544,7 @@ __global__ __launch_bounds__(kTraceThreads) void traceKernel(const TraceArgs a)
             }
             if (done)
             {
-                if (recordSlot >= 0)
+                if (Record && recordSlot >= 0)
                 {
                     a.records.castsValid[2 * recordSlot + 0] = casts;
                     a.records.castsValid[2 * recordSlot + 1] = valid;
@@ -830,16 +837,50 @@ size_t stackBytes(const SceneView& scene, int threads)
 
 }  // namespace
 
+#ifdef RT_DIAG
+void printDiagnostics()
+{
+    unsigned long long host[16] = {};
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_rtDiag), sizeof(host)) != hipSuccess) return;
+    const char* names[] = {"mesh casts", "outer rounds", "node steps", "triangle tests", "main loop", "keep tests"};
+    for (int k = 0; k < 6; ++k)
+    {
+        fprintf(stderr, "[rt diag] %-15s wave trips %12llu  active lanes %14llu  (%.1f / 64)\n", names[k], host[2 * k],
+                host[2 * k + 1], host[2 * k] ? static_cast<double>(host[2 * k + 1]) / host[2 * k] : 0.0);
+    }
+    unsigned long long zero[16] = {};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_rtDiag), zero, sizeof(zero));
+}
+#endif
+
 void launchTrace(const TraceArgs& args, int blocks, int threads, hipStream_t stream)
 {
     (void)threads;
-    hipLaunchKernelGGL(traceKernel, dim3(blocks), dim3(kTraceThreads), stackBytes(args.scene, kTraceThreads), stream, args);
+    const dim3 grid(blocks), block(kTraceThreads);
+    const size_t lds = stackBytes(args.scene, kTraceThreads);
+    const bool record = args.records.recordPhotons > 0;
+    switch (args.sinkMode)
+    {
+    case kSinkProbe:
+        if (record) hipLaunchKernelGGL((traceKernel<kSinkProbe, true>), grid, block, lds, stream, args);
+        else hipLaunchKernelGGL((traceKernel<kSinkProbe, false>), grid, block, lds, stream, args);
+        break;
+    case kSinkSplat:
+        if (record) hipLaunchKernelGGL((traceKernel<kSinkSplat, true>), grid, block, lds, stream, args);
+        else hipLaunchKernelGGL((traceKernel<kSinkSplat, false>), grid, block, lds, stream, args);
+        break;
+    default:
+        if (record) hipLaunchKernelGGL((traceKernel<kSinkNone, true>), grid, block, lds, stream, args);
+        else hipLaunchKernelGGL((traceKernel<kSinkNone, false>), grid, block, lds, stream, args);
+        break;
+    }
 }
 
 int traceBlocksPerCu(const SceneView& scene)
 {
     int blocks = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, traceKernel, kTraceThreads,
+    // the grid is sized by the variant with the largest register footprint
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, traceKernel<kSinkSplat, true>, kTraceThreads,
                                                      stackBytes(scene, kTraceThreads)) != hipSuccess ||
         blocks < 1)
     {

@@ -66,7 +66,8 @@ _SIGNATURES = {
 }
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-TRACER_LIB_PATH = os.path.join(_HERE, "csrc", "librt_amd.so")
+# RT_AMD_LIBRARY selects another build of the same library (e.g. the census build)
+TRACER_LIB_PATH = os.environ.get("RT_AMD_LIBRARY") or os.path.join(_HERE, "csrc", "librt_amd.so")
 _lib = None
 
 
