@@ -39,6 +39,11 @@ MANIFEST = {
     "render_furnace": {"scene": "tests/scenes/furnace.json", "photons_per_light": 3000, "fetch_size": 50000},
     "emit": {"scene": "tests/scenes/mixed.json", "n": 64, "seed": 99},
     "probes_mixed": {"scene": "tests/scenes/mixed.json"},
+    # a whole deterministic frame in probe mode: probe pass, emitter deposits, photon pass,
+    # gather, tonemap (mixed.json keeps every deposit; the tighter radius exercises the cull)
+    "render_mixed": {"scene": "tests/scenes/mixed.json", "photons_per_light": 2500, "fetch_size": 50000},
+    "render_mixed_tight": {"scene": "tests/scenes/mixed.json", "photons_per_light": 2500, "fetch_size": 50000,
+                           "probe_keep_radius_scale": 2.0},
     "probes_bombardment": {"scene": "scenes/MirrorBombardment-200M.json", "image": 96, "probe_sub_sample": 1,
                            "seed": 11},
 }
@@ -62,6 +67,8 @@ def write_scene(rt, entry, path):
         s.fetch_size = entry["fetch_size"]
     if "seed" in entry:
         s.seeded, s.seed = 1, entry["seed"]
+    if "probe_keep_radius_scale" in entry:
+        s.probe_keep_radius_scale = entry["probe_keep_radius_scale"]
     if "probe_sub_sample" in entry:
         s.probe_sub_sample = entry["probe_sub_sample"]
     if "image" in entry:  # shrink every camera to image x image pixels
@@ -124,6 +131,22 @@ def main():
         keep = {k: arrays[k] for k in ("render_counters", "render_ledger", "render_crosscheck")}
         keep["render_store_head"] = arrays["render_store_head"][:4096]
         np.savez_compressed(os.path.join(GOLDEN, "render_furnace.npz"), **keep)
+
+        # ---- whole frames in probe mode ----
+        for key in ("render_mixed", "render_mixed_tight"):
+            scene_path = os.path.join(tmp, key + ".rtsb")
+            write_scene(rt, MANIFEST[key], scene_path)
+            d = os.path.join(tmp, key)
+            os.makedirs(d)
+            run(REFDUMP, "render", scene_path, d)
+            arrays = load_dir(d)
+            keep = {k: v for k, v in arrays.items()
+                    if k.startswith(("render_buffer_c", "render_image_c", "render_gather_c"))
+                    or k in ("render_counters", "render_ledger", "render_crosscheck", "render_store")}
+            for k in list(keep):
+                if k.startswith("render_image_c"):
+                    keep[k] = keep[k].astype(np.uint16)
+            np.savez_compressed(os.path.join(GOLDEN, key + ".npz"), **keep)
 
         # ---- probe pass ----
         for key in ("probes_mixed", "probes_bombardment"):

@@ -2121,6 +2121,12 @@ int orc_trace(orc_context* ctx, const orc_trace_config* config, orc_trace_result
             probeIndex.build(cfg.probes, cfg.probe_count, cfg.probe_cell_size, cfg.keep_radius);
             sh.probeIndex = &probeIndex;
             ctx->store.reset(cfg.store_capacity);
+            for (std::uint64_t i = 0; i < cfg.preload_count; ++i)
+            {
+                RawBounce r;
+                std::memcpy(&r, cfg.preload + 13 * i, sizeof(r));
+                ctx->store.append(r);
+            }
         }
         else
         {
@@ -2443,6 +2449,339 @@ std::int64_t orc_collect_gather_points(orc_context* ctx, std::int32_t camera, st
     for (int i = 0; i < 3; ++i) ctx->gatherRows.push_back(static_cast<double>(counts[i]));
     *rows = ctx->gatherRows.data();
     return static_cast<std::int64_t>(points.size());
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------ emitter deposits and the gather
+namespace
+{
+
+constexpr float kEmitterTimeless = std::numeric_limits<float>::infinity();  // include/BounceStore.h:57
+
+// src/ProbeGather.cpp:464-550
+void depositEmitters(const orc_context& ctx, const ProbeIndex& probeIndex, double depositSpacing,
+                     std::vector<RawBounce>& out, std::uint64_t stats[3])
+{
+    const std::vector<EmitterPatch> patches = collectEmitterPatches(ctx);
+    stats[0] = patches.size();
+    const double spacing = std::max(depositSpacing, 1e-6);
+    for (const EmitterPatch& patch : patches)
+    {
+        const double extentU = patch.isDisc ? patch.radius : patch.halfWidth;
+        const double extentV = patch.isDisc ? patch.radius : patch.halfHeight;
+        if (extentU <= 0.0 || extentV <= 0.0)
+        {
+            continue;
+        }
+        const int countU = std::max(1, static_cast<int>(std::ceil(2.0 * extentU / spacing)));
+        const int countV = std::max(1, static_cast<int>(std::ceil(2.0 * extentV / spacing)));
+        const double stepU = (2.0 * extentU) / countU;
+        const double stepV = (2.0 * extentV) / countV;
+        const double area =
+            patch.isDisc ? (kPi * patch.radius * patch.radius) : (2.0 * patch.halfWidth) * (2.0 * patch.halfHeight);
+        std::vector<Vec> samples;
+        for (int iu = 0; iu < countU; ++iu)
+        {
+            const double u = -extentU + (iu + 0.5) * stepU;
+            for (int iv = 0; iv < countV; ++iv)
+            {
+                const double v = -extentV + (iv + 0.5) * stepV;
+                if (patch.isDisc && (u * u + v * v) > (patch.radius * patch.radius))
+                {
+                    continue;
+                }
+                samples.push_back(patch.center + patch.right * u + patch.up * v);
+            }
+        }
+        if (samples.empty())
+        {
+            continue;
+        }
+        stats[1] += samples.size();
+        const double perDepositScale = (kPi * area) / (4.0 * static_cast<double>(samples.size()));
+        const Color perDepositPower = patch.radiance * static_cast<float>(perDepositScale);
+        for (const Vec& position : samples)
+        {
+            if (!probeIndex.anyWithin(position, probeIndex.keepRadius))
+            {
+                continue;
+            }
+            RawBounce r;
+            r.px = static_cast<float>(position.x);
+            r.py = static_cast<float>(position.y);
+            r.pz = static_cast<float>(position.z);
+            r.ix = r.nx = static_cast<float>(patch.normal.x);
+            r.iy = r.ny = static_cast<float>(patch.normal.y);
+            r.iz = r.nz = static_cast<float>(patch.normal.z);
+            r.time = kEmitterTimeless;
+            r.power[0] = perDepositPower.red;
+            r.power[1] = perDepositPower.green;
+            r.power[2] = perDepositPower.blue;
+            out.push_back(r);
+            stats[2] += 1;
+        }
+    }
+}
+
+// BounceStore::buildIndex / radiusSearch, src/BounceStore.cpp:42-98.  The reference walks
+// the (2 reach + 1)^3 cells around the query in dz / dy / dx order and looks each one up in
+// a hash map.  Here the occupied cells are kept sorted by (z, y, x), which is that same
+// order, so a query whose cube holds more cells than the store occupies walks the
+// occupied cells of the cube instead: same neighbours, same order, without the empty lookups.
+struct ZyxLess
+{
+    bool operator()(const CellKey& a, const CellKey& b) const
+    {
+        return std::tie(a.z, a.y, a.x) < std::tie(b.z, b.y, b.x);
+    }
+};
+
+struct BounceIndex
+{
+    const RawBounce* records = nullptr;
+    double invCellSize = 1.0;
+    std::map<CellKey, std::vector<size_t>, ZyxLess> cells;
+
+    CellKey cellOf(const Vec& p) const
+    {
+        return {static_cast<std::int64_t>(std::floor(p.x * invCellSize)),
+                static_cast<std::int64_t>(std::floor(p.y * invCellSize)),
+                static_cast<std::int64_t>(std::floor(p.z * invCellSize))};
+    }
+    void build(const RawBounce* r, size_t count, double cellSize)
+    {
+        records = r;
+        invCellSize = 1.0 / (cellSize > 0.0 ? cellSize : 1.0);
+        cells.clear();
+        for (size_t i = 0; i < count; ++i)
+        {
+            cells[cellOf(Vec{r[i].px, r[i].py, r[i].pz})].push_back(i);
+        }
+    }
+    void scanCell(const std::vector<size_t>& members, const Vec& p, double r2, std::vector<size_t>& result) const
+    {
+        for (const size_t index : members)
+        {
+            const RawBounce& rec = records[index];
+            const double ddx = static_cast<double>(rec.px) - p.x;
+            const double ddy = static_cast<double>(rec.py) - p.y;
+            const double ddz = static_cast<double>(rec.pz) - p.z;
+            if (ddx * ddx + ddy * ddy + ddz * ddz <= r2)
+            {
+                result.push_back(index);
+            }
+        }
+    }
+    void radiusSearch(const Vec& p, double r, std::vector<size_t>& result) const
+    {
+        result.clear();
+        if (r <= 0.0 || cells.empty())
+        {
+            return;
+        }
+        const double r2 = r * r;
+        const CellKey center = cellOf(p);
+        const std::int64_t reach = static_cast<std::int64_t>(std::ceil(r * invCellSize));
+        const double side = 2.0 * static_cast<double>(reach) + 1.0;
+        if (side * side * side > static_cast<double>(cells.size()))
+        {
+            const CellKey lo{center.x - reach, center.y - reach, center.z - reach};
+            const CellKey hi{center.x + reach, center.y + reach, center.z + reach};
+            for (auto it = cells.lower_bound(lo); it != cells.end() && !ZyxLess()(hi, it->first); ++it)
+            {
+                const CellKey& k = it->first;
+                if (k.x < lo.x || k.x > hi.x || k.y < lo.y || k.y > hi.y)
+                {
+                    continue;
+                }
+                scanCell(it->second, p, r2, result);
+            }
+            return;
+        }
+        for (std::int64_t dz = -reach; dz <= reach; ++dz)
+            for (std::int64_t dy = -reach; dy <= reach; ++dy)
+                for (std::int64_t dx = -reach; dx <= reach; ++dx)
+                {
+                    const auto it = cells.find(CellKey{center.x + dx, center.y + dy, center.z + dz});
+                    if (it == cells.end()) continue;
+                    scanCell(it->second, p, r2, result);
+                }
+    }
+};
+
+// testing::gatherRadiance, src/ProbeGather.cpp:596-728
+Color gatherRadiance(const orc_context& ctx, const BounceIndex& index, const GatherPoint& gp, double minGatherRadius,
+                     float timeHalfWindow, std::vector<size_t>& neighbors, std::uint64_t& outDeposits)
+{
+    outDeposits = 0;
+    const bool isEmitter = gp.material == kEmitterMaterial;
+    const Vec& wo = gp.viewDir;
+    if (dot(wo, gp.normal) <= 0.0)
+    {
+        return Color{0.0f, 0.0f, 0.0f};
+    }
+    const double r = (minGatherRadius > 0.0 && gp.footprintRadius < minGatherRadius) ? minGatherRadius
+                                                                                     : gp.footprintRadius;
+    if (r <= 0.0)
+    {
+        return Color{0.0f, 0.0f, 0.0f};
+    }
+    index.radiusSearch(gp.position, r, neighbors);
+    if (neighbors.empty())
+    {
+        return Color{0.0f, 0.0f, 0.0f};
+    }
+    constexpr double kNormalAgree = 0.5;
+    const double planeBand = 2.0 * r;
+    Color sum{0.0f, 0.0f, 0.0f};
+    std::uint64_t kept = 0;
+    for (const size_t i : neighbors)
+    {
+        const RawBounce& record = index.records[i];
+        if (record.time != kEmitterTimeless && std::abs(record.time - gp.sampleTime) > timeHalfWindow)
+        {
+            continue;
+        }
+        const Vec dn{record.nx, record.ny, record.nz};
+        if (isEmitter)
+        {
+            if (dot(dn, gp.normal) < kNormalAgree)
+            {
+                continue;
+            }
+            sum.red += record.power[0];
+            sum.green += record.power[1];
+            sum.blue += record.power[2];
+            ++kept;
+            continue;
+        }
+        const double dnLen = magnitude(dn);
+        if (dnLen > 1e-4)
+        {
+            if (dot(dn / dnLen, gp.normal) < kNormalAgree)
+            {
+                continue;
+            }
+        }
+        const double planeDist = std::abs(dot(Vec{record.px, record.py, record.pz} - gp.position, gp.normal));
+        if (planeDist > planeBand)
+        {
+            continue;
+        }
+        const Vec wi = -Vec{record.ix, record.iy, record.iz};
+        const Color f = evaluateMaterial(ctx.materials[gp.material], wi, wo, gp.normal);
+        const Color fp = f * Color{record.power[0], record.power[1], record.power[2]};
+        sum.red += fp.red;
+        sum.green += fp.green;
+        sum.blue += fp.blue;
+        ++kept;
+    }
+    outDeposits = kept;
+    if (kept == 0)
+    {
+        return Color{0.0f, 0.0f, 0.0f};
+    }
+    const double kSplatParity = 4.0 / kPi;
+    const double area = kPi * r * r;
+    const float scale = static_cast<float>(kSplatParity / area);
+    return sum * scale;
+}
+
+}  // namespace
+
+extern "C" {
+
+std::int64_t orc_deposit_emitters(const orc_context* ctx, const double* probes, std::uint64_t probe_count,
+                                  double probe_cell_size, double keep_radius, double spacing, float* records,
+                                  std::uint64_t capacity, std::uint64_t* stats3)
+{
+    ProbeIndex index;
+    index.build(probes, probe_count, probe_cell_size, keep_radius);
+    std::vector<RawBounce> out;
+    std::uint64_t stats[3] = {0, 0, 0};
+    depositEmitters(*ctx, index, spacing, out, stats);
+    if (stats3) std::memcpy(stats3, stats, sizeof(stats));
+    const std::uint64_t n = std::min<std::uint64_t>(capacity, out.size());
+    if (n > 0) std::memcpy(records, out.data(), n * sizeof(RawBounce));
+    return static_cast<std::int64_t>(out.size());
+}
+
+std::int32_t orc_gather(orc_context* ctx, std::int32_t camera, std::int32_t rng_mode, std::int32_t math_mode,
+                        const float* store, std::uint64_t store_count, double gather_cell_size,
+                        double min_gather_radius, float* buffer, std::uint64_t* stats4)
+{
+    if (camera < 0 || static_cast<size_t>(camera) >= ctx->cameras.size())
+    {
+        return 1;
+    }
+    std::uint64_t counts[3] = {0, 0, 0};
+    const std::vector<GatherPoint> points = (math_mode == ORC_MATH_LIBM)
+                                                ? collectGatherPoints<LibmMath>(*ctx, camera, rng_mode, counts)
+                                                : collectGatherPoints<PortableMath>(*ctx, camera, rng_mode, counts);
+    BounceIndex index;
+    index.build(reinterpret_cast<const RawBounce*>(store), store_count, gather_cell_size);
+    const Camera& cam = ctx->cameras[camera];
+    const size_t width = static_cast<size_t>(cam.d.width), height = static_cast<size_t>(cam.d.height);
+    const float timeHalfWindow = std::max(0.0f, static_cast<float>(ctx->settings.shutter_time));
+    std::vector<size_t> neighbors;
+    std::uint64_t gathered = 0, depositsAccum = 0;
+    // ProbeGather::run / gatherRecords, src/ProbeGather.cpp:865-994 (one thread)
+    for (const GatherPoint& gp : points)
+    {
+        if (gp.material != kEmitterMaterial &&
+            (gp.material < 0 || static_cast<size_t>(gp.material) >= ctx->materials.size()))
+        {
+            continue;
+        }
+        std::uint64_t deposits = 0;
+        const Color radiance = gatherRadiance(*ctx, index, gp, min_gather_radius, timeHalfWindow, neighbors, deposits);
+        const Color contribution = gp.throughput * radiance * gp.sampleWeight;
+        depositsAccum += deposits;
+        if (contribution.red == 0.0f && contribution.green == 0.0f && contribution.blue == 0.0f)
+        {
+            continue;
+        }
+        const size_t at = ((gp.py * width) + gp.px) * 3;  // Buffer::addColor, src/Buffer.cpp:22-37
+        if (at + 2 >= width * height * 3)
+        {
+            continue;
+        }
+        buffer[at + 0] += contribution.red;
+        buffer[at + 1] += contribution.green;
+        buffer[at + 2] += contribution.blue;
+        ++gathered;
+    }
+    if (stats4)
+    {
+        stats4[0] = points.size();
+        stats4[1] = gathered;
+        stats4[2] = depositsAccum;
+        stats4[3] = 0;
+    }
+    return 0;
+}
+
+void orc_tonemap(const float* buffer, std::int32_t width, std::int32_t height, double saturation_luminance,
+                 std::uint16_t* image)
+{
+    const double invLmax = (saturation_luminance > 0.0) ? (1.0 / saturation_luminance) : 0.0;
+    const float invGamma = 1.0f / 2.2f;  // Color::gamma, include/Color.h
+    for (std::int32_t y = 0; y < height; ++y)
+    {
+        for (std::int32_t x = 0; x < width; ++x)
+        {
+            const float* c = buffer + (static_cast<size_t>(y) * width + x) * 3;
+            std::uint16_t* out =
+                image + (static_cast<size_t>(height - 1 - y) * width + static_cast<size_t>(width - 1 - x)) * 3;
+            for (int k = 0; k < 3; ++k)
+            {
+                const double exposed = c[k] * invLmax;
+                const float g = std::pow(static_cast<float>(exposed), invGamma);
+                out[k] = static_cast<std::uint16_t>(std::min(static_cast<int>(g * 65535), 65535));
+            }
+        }
+    }
 }
 
 }  // extern "C"

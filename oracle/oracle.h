@@ -52,6 +52,10 @@ typedef struct orc_trace_config
     /* sink B inputs */
     double min_splat_radius;
     double density_cell_size; /* <= 0: no density grid */
+    /* records appended to the store before the photon pass (emitter deposits,
+     * reference src/Renderer.cpp:394-418); 13 floats each */
+    const float* preload;
+    uint64_t preload_count;
 } orc_trace_config;
 
 typedef struct orc_trace_result
@@ -117,6 +121,24 @@ void orc_emit_mt(const orc_context* ctx, int32_t light, int64_t n, uint32_t seed
  * keeps the array owned by the context. */
 int64_t orc_collect_gather_points(orc_context* ctx, int32_t camera, int32_t rng_mode,
                                   int32_t math_mode, const double** rows);
+
+/* ProbeGather::depositEmitters (reference src/ProbeGather.cpp:464-550): the deposits of
+ * every emitter patch that pass the probe keep-test, in the reference's order, 13 floats
+ * each, at most `capacity`.  stats3 receives patches, generated, kept.  Returns kept. */
+int64_t orc_deposit_emitters(const orc_context* ctx, const double* probes, uint64_t probe_count, double probe_cell_size,
+                             double keep_radius, double spacing, float* records, uint64_t capacity, uint64_t* stats3);
+
+/* BounceStore::buildIndex + ProbeGather::run (reference src/BounceStore.cpp:42-98,
+ * src/ProbeGather.cpp:596-728,865-994) for one camera over the given store records, single
+ * threaded: the camera's gather points are produced with the given draw / math modes, then
+ * gathered into buffer ([h][w][3], must be zeroed by the caller).  stats4 receives
+ * pixelsHit, pixelsGathered, depositsAccum, (unused). */
+int32_t orc_gather(orc_context* ctx, int32_t camera, int32_t rng_mode, int32_t math_mode, const float* store,
+                   uint64_t store_count, double gather_cell_size, double min_gather_radius, float* buffer,
+                   uint64_t* stats4);
+
+/* Renderer::tonemapBufferToImage (reference src/Renderer.cpp:40-76): [h][w][3] float -> [h][w][3] u16, flipped. */
+void orc_tonemap(const float* buffer, int32_t width, int32_t height, double saturation_luminance, uint16_t* image);
 
 #ifdef __cplusplus
 }

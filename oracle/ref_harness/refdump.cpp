@@ -1040,6 +1040,40 @@ int modeRender(const std::string& scenePath, const std::string& dir)
     };
     npy::writeF64(dir + "/render_counters.npy", counters, {counters.size()});
 
+    // per-camera composited float buffers, tonemapped images and gather diagnostics
+    for (size_t c = 0; c < result.cameras.size(); ++c)
+    {
+        const CameraRender& cr = result.cameras[c];
+        if (!cr.buffer || !cr.image || !cr.camera) continue;
+        const size_t w = cr.camera->width(), h = cr.camera->height();
+        std::vector<float> pixels;
+        std::vector<int32_t> image;
+        pixels.reserve(w * h * 3);
+        image.reserve(w * h * 3);
+        for (size_t y = 0; y < h; ++y)
+        {
+            for (size_t x = 0; x < w; ++x)
+            {
+                const Color col = cr.buffer->fetchColor({x, y});
+                pixels.insert(pixels.end(), {col.red, col.green, col.blue});
+                const Pixel& px = cr.image->getPixel(x, y);
+                image.insert(image.end(), {static_cast<int32_t>(px.red), static_cast<int32_t>(px.green),
+                                           static_cast<int32_t>(px.blue)});
+            }
+        }
+        npy::writeF32(dir + "/render_buffer_c" + std::to_string(c) + ".npy", pixels, {h, w, 3});
+        npy::writeI32(dir + "/render_image_c" + std::to_string(c) + ".npy", image, {h, w, 3});
+        std::vector<double> probe = {static_cast<double>(cr.probe.pixelsHit), static_cast<double>(cr.probe.pixelsGathered),
+                                     static_cast<double>(cr.probe.depositsAccum), cr.camera->saturationLuminance()};
+        npy::writeF64(dir + "/render_gather_c" + std::to_string(c) + ".npy", probe, {probe.size()});
+    }
+    if (result.bounceStore && result.bounceStore->size() <= (1u << 20))
+    {
+        std::vector<RawBounce> all;
+        for (size_t i = 0; i < result.bounceStore->size(); ++i) all.push_back((*result.bounceStore)[i]);
+        writeDeposits(dir + "/render_store.npy", all);
+    }
+
     if (result.bounceStore)
     {
         const size_t n = result.bounceStore->size();

@@ -54,7 +54,7 @@ def open_scene(rt, entry):
     if "seed" in entry and "seeded" not in entry:
         s.seeded = 1
     for key in ("use_probe_gather", "bounce_threshold", "seed", "seeded", "deterministic", "probe_sub_sample",
-                "camera_time_samples", "shutter_time", "frame_time"):
+                "camera_time_samples", "shutter_time", "frame_time", "probe_keep_radius_scale"):
         if key in entry:
             setattr(s, key, entry[key])
     if "image" in entry:  # every camera shrunk to image x image pixels

@@ -19,7 +19,7 @@ class TraceConfig(C.Structure):
         ("first_photon", C.c_uint64), ("photon_count", C.c_uint64), ("record_photons", C.c_uint64),
         ("probes", C.c_void_p), ("probe_count", C.c_uint64), ("probe_cell_size", C.c_double),
         ("keep_radius", C.c_double), ("store_capacity", C.c_uint64), ("min_splat_radius", C.c_double),
-        ("density_cell_size", C.c_double),
+        ("density_cell_size", C.c_double), ("preload", C.c_void_p), ("preload_count", C.c_uint64),
     ]
 
 
@@ -59,6 +59,14 @@ def lib():
         L.orc_collect_gather_points.restype = C.c_int64
         L.orc_collect_gather_points.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                                 C.POINTER(C.POINTER(C.c_double))]
+        L.orc_deposit_emitters.restype = C.c_int64
+        L.orc_deposit_emitters.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_double, C.c_double, C.c_double,
+                                           C.c_void_p, C.c_uint64, C.c_void_p]
+        L.orc_gather.restype = C.c_int32
+        L.orc_gather.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_uint64, C.c_double,
+                                 C.c_double, C.c_void_p, C.c_void_p]
+        L.orc_tonemap.restype = None
+        L.orc_tonemap.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_void_p]
         _lib = L
     return _lib
 
@@ -138,9 +146,31 @@ class Oracle:
             parts.append(self.collect_gather_points(c, rng_mode, math_mode)[0][:, 2:5])
         return np.ascontiguousarray(np.concatenate(parts, axis=0))
 
+    def deposit_emitters(self, probes, probe_cell_size, keep_radius, spacing, capacity=1 << 22):
+        """(records[n, 13], stats) of ProbeGather::depositEmitters against the given probes."""
+        probes = np.ascontiguousarray(probes, dtype=np.float64).reshape(-1, 3)
+        out = np.zeros((capacity, 13), dtype=np.float32)
+        stats = np.zeros(3, dtype=np.uint64)
+        n = lib().orc_deposit_emitters(self.ctx, _ptr(probes), probes.shape[0], probe_cell_size, keep_radius, spacing,
+                                       _ptr(out), capacity, _ptr(stats))
+        return out[:min(n, capacity)].copy(), dict(zip(("patches", "generated", "kept"), (int(v) for v in stats)))
+
+    def gather(self, camera, store, gather_cell_size, min_gather_radius, rng_mode=RNG_COUNTER,
+               math_mode=MATH_PORTABLE):
+        """(buffer[h, w, 3], stats) of the store index build + ProbeGather::run for one camera."""
+        cam = self.scene.desc.cameras[camera]
+        store = np.ascontiguousarray(store, dtype=np.float32).reshape(-1, 13)
+        buffer = np.zeros((cam.height, cam.width, 3), dtype=np.float32)
+        stats = np.zeros(4, dtype=np.uint64)
+        if lib().orc_gather(self.ctx, camera, rng_mode, math_mode, _ptr(store), store.shape[0], gather_cell_size,
+                            min_gather_radius, _ptr(buffer), _ptr(stats)) != 0:
+            raise RuntimeError("orc_gather failed")
+        names = ("pixels_hit", "pixels_gathered", "deposits_accum")
+        return buffer, dict(zip(names, (int(v) for v in stats[:3])))
+
     def trace(self, rng_mode=RNG_COUNTER, math_mode=MATH_PORTABLE, sink_mode=SINK_NONE, threads=1,
               first_photon=0, photon_count=0, record_photons=0, probes=None, probe_cell_size=0.0,
-              keep_radius=0.0, store_capacity=0, min_splat_radius=0.0, density_cell_size=0.0):
+              keep_radius=0.0, store_capacity=0, min_splat_radius=0.0, density_cell_size=0.0, preload=None):
         cfg = TraceConfig()
         cfg.rng_mode, cfg.math_mode, cfg.sink_mode, cfg.threads = rng_mode, math_mode, sink_mode, threads
         cfg.first_photon, cfg.photon_count, cfg.record_photons = first_photon, photon_count, record_photons
@@ -151,10 +181,38 @@ class Oracle:
             cfg.probe_count = keep_alive.shape[0]
         cfg.probe_cell_size, cfg.keep_radius, cfg.store_capacity = probe_cell_size, keep_radius, store_capacity
         cfg.min_splat_radius, cfg.density_cell_size = min_splat_radius, density_cell_size
+        keep_preload = None
+        if preload is not None and len(preload):
+            keep_preload = np.ascontiguousarray(preload, dtype=np.float32).reshape(-1, 13)
+            cfg.preload = keep_preload.ctypes.data
+            cfg.preload_count = keep_preload.shape[0]
         res = TraceResult()
         if lib().orc_trace(self.ctx, C.byref(cfg), C.byref(res)) != 0:
             raise RuntimeError(lib().orc_last_error().decode())
         return unpack_result(res, self.scene)
+
+
+def tonemap(buffer, saturation_luminance):
+    """Renderer::tonemapBufferToImage restated: float [h, w, 3] -> uint16 [h, w, 3], flipped in x and y."""
+    buffer = np.ascontiguousarray(buffer, dtype=np.float32)
+    h, w, _ = buffer.shape
+    image = np.zeros((h, w, 3), dtype=np.uint16)
+    lib().orc_tonemap(_ptr(buffer), w, h, saturation_luminance, _ptr(image))
+    return image
+
+
+def frame_setup(orc, rng_mode, math_mode):
+    """Probe positions, keep radius, store capacity, emitter spacing, gather cell and gather
+    radius floor as Renderer::renderFrame derives them (reference src/Renderer.cpp:222-419,624-641)."""
+    d = orc.derive()
+    s = orc.scene.settings
+    probes = orc.collect_probe_positions(rng_mode, math_mode)
+    capacity = int(s.bounce_store_capacity)
+    if probes.shape[0]:
+        capacity = min(capacity, max(1, probes.shape[0] * 256))
+    cell = d["scene_depth_footprint"] if d["scene_depth_footprint"] > 0.0 else d["cell_size"]
+    return dict(d, probes=probes, store_capacity=capacity, emitter_spacing=max(cell * 0.5, 1e-6), gather_cell=cell,
+                min_gather_radius=d["min_splat_radius"])
 
 
 def unpack_result(res, scene):

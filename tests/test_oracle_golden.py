@@ -213,3 +213,39 @@ def test_probe_pass_counter_mode_differs_only_in_stochastic_samples(manifest, sc
         if q is not None and q[11] == r[11] and np.allclose(q[2:5], r[2:5], rtol=0, atol=1e-9):
             same += 1
     assert same > 0.9 * common
+
+
+@pytest.mark.parametrize("key", ["render_mixed", "render_mixed_tight"])
+def test_whole_probe_mode_frame_matches_reference(golden, manifest, scene_opener, key):
+    """Renderer::renderFrame in deterministic probe mode, stage by stage against the reference's
+    own output: emitter deposits + photon deposits (the store, record for record), every
+    camera's gathered float buffer and its tonemapped 16-bit image, bit for bit."""
+    g = golden(key)
+    scene = scene_opener(manifest[key])
+    orc = O.Oracle(scene)
+    setup = O.frame_setup(orc, O.RNG_MT, O.MATH_LIBM)
+    counters = g["render_counters"]
+    assert setup["store_capacity"] == int(counters[5])
+    emitters, estats = orc.deposit_emitters(setup["probes"], setup["keep_radius"], setup["keep_radius"],
+                                            setup["emitter_spacing"])
+    assert estats["kept"] == int(counters[6]) and estats["kept"] > 0
+    r = orc.trace(rng_mode=O.RNG_MT, math_mode=O.MATH_LIBM, sink_mode=O.SINK_PROBE, probes=setup["probes"],
+                  probe_cell_size=setup["keep_radius"], keep_radius=setup["keep_radius"],
+                  store_capacity=setup["store_capacity"], preload=emitters)
+    assert (r["kept"], r["culled"]) == (int(counters[0]), int(counters[1]))
+    assert_bits_equal(r["store"], g["render_store"], "store")
+    desc = scene.desc
+    for c in range(desc.camera_count):
+        cam = desc.cameras[c]
+        want = g[f"render_buffer_c{c}"]
+        if cam.bounce_filter >= 0 or cam.light_filter >= 0:
+            got = np.zeros_like(want)
+        else:
+            got, stats = orc.gather(c, r["store"], setup["gather_cell"], setup["min_gather_radius"], O.RNG_MT,
+                                    O.MATH_LIBM)
+            hit, gathered, accum = (int(v) for v in g[f"render_gather_c{c}"][:3])
+            assert (stats["pixels_hit"], stats["pixels_gathered"], stats["deposits_accum"]) == (hit, gathered, accum)
+            assert gathered > 0
+        assert_bits_equal(got, want, f"{key} camera {c} buffer")
+        image = O.tonemap(got, float(g[f"render_gather_c{c}"][3]))
+        assert np.array_equal(image, g[f"render_image_c{c}"]), "tonemapped image"
