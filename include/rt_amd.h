@@ -156,6 +156,23 @@ int32_t rt_read_records(rt_tracer* tracer, uint64_t* recorded, double* emitted, 
 int32_t rt_collect_gather_points(rt_tracer* tracer, int32_t camera, double* rows19, uint64_t capacity,
                                  uint64_t* count, uint64_t* stats3);
 
+/* BounceStore::append for n host records of 13 floats (position, incoming direction, normal,
+ * time, power; reference include/BounceStore.h:55-113, src/BounceStore.cpp:11-20): the cursor
+ * advances by n, records beyond the capacity are dropped and counted.  Called after rt_reset
+ * and before rt_trace it places the emitter deposits ahead of the photon deposits, as
+ * Renderer::renderFrame does (reference src/Renderer.cpp:394-418). */
+int32_t rt_store_append(rt_tracer* tracer, const float* records13, uint64_t n);
+
+/* BounceStore::buildIndex + ProbeGather::run for one camera (reference src/BounceStore.cpp:42-98,
+ * src/ProbeGather.cpp:596-728,865-994; call site src/Renderer.cpp:624-641,698-723): indexes the
+ * store of the last pass by cells of gather_cell_size, then adds every gather point's density
+ * estimate (footprint floored at min_gather_radius, temporal window = the scene's shutter) into the
+ * camera buffer.  stats4 (optional) receives pixelsHit, pixelsGathered, depositsAccum
+ * (reference include/ProbeGather.h:106-125) and the number of records left out of the index
+ * because their cell exceeds +-2^20. */
+int32_t rt_gather(rt_tracer* tracer, int32_t camera, double gather_cell_size, double min_gather_radius,
+                  uint64_t* stats4);
+
 /* ProbeIndex::anyWithinKeepRadius (reference src/ProbeIndex.cpp:48-83) for n host points
  * (xyz doubles) against the probes given to rt_set_probes; keep[i] = 1 when a probe lies
  * within the keep radius.  Used for the emitter deposits of src/ProbeGather.cpp:520-545. */

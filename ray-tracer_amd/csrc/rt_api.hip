@@ -166,13 +166,17 @@ struct rt_tracer
 
     // probe pass
     DeviceArray<rtd::EmitterPatch> patches;
-    struct GatherCache
+    struct GatherCache  // one camera's probe pass, kept on the device for the gather
     {
         bool valid = false;
+        int64_t pixels = 0;
+        DeviceArray<uint32_t> counts;
+        DeviceArray<uint64_t> offsets;
+        DeviceArray<rtd::GatherPoint> devicePoints;
         std::vector<rtd::GatherPoint> points;
         uint64_t stats[3] = {0, 0, 0};
     };
-    std::vector<GatherCache> gatherCache;
+    std::vector<std::unique_ptr<GatherCache>> gatherCache;
 
     rtd::SceneView view{};
     int blocks = 0;
@@ -399,7 +403,11 @@ void buildScene(rt_tracer* t, const rt_scene* scene)
         patches.push_back(patch);
     }
     t->patches.upload(patches);
-    t->gatherCache.assign(static_cast<size_t>(scene->camera_count), rt_tracer::GatherCache{});
+    t->gatherCache.clear();
+    for (int64_t i = 0; i < scene->camera_count; ++i)
+    {
+        t->gatherCache.emplace_back(new rt_tracer::GatherCache());
+    }
 
     t->volumes.upload(volumes);
     t->nodes.upload(nodes);
@@ -424,6 +432,7 @@ void buildScene(rt_tracer* t, const rt_scene* scene)
     view.volumeCount = static_cast<int32_t>(volumes.size());
     view.lightCount = static_cast<int32_t>(lights.size());
     view.cameraCount = static_cast<int32_t>(t->cameraHost.size());
+    view.materialCount = static_cast<int32_t>(materials.size());
     view.bounceThreshold = scene->settings.bounce_threshold;
     view.terminationThreshold = std::max(0.0, scene->settings.termination_threshold);  // reference src/Worker.cpp:194-199
     view.splatLuminanceClamp = std::max(0.0, scene->settings.splat_luminance_clamp);
@@ -473,6 +482,63 @@ uint64_t cellSlot(const CellKey& k, uint64_t mask)
     h ^= static_cast<uint64_t>(k.y) * 19349663ull;
     h ^= static_cast<uint64_t>(k.z) * 83492791ull;
     return ((h * 0x9E3779B97F4A7C15ull) >> 20) & mask;
+}
+
+// Runs the probe pass of one camera once and keeps its records on the device (for the
+// gather) and on the host (for rt_collect_gather_points).
+rt_tracer::GatherCache& ensureGatherPoints(rt_tracer* tracer, int32_t camera)
+{
+    rt_tracer::GatherCache& cache = *tracer->gatherCache[static_cast<size_t>(camera)];
+    if (cache.valid)
+    {
+        return cache;
+    }
+    const rtd::Camera& cam = tracer->cameraHost[camera];
+    const int32_t stride = static_cast<int32_t>(std::max<uint64_t>(1, tracer->settings.probe_sub_sample));
+    const int64_t gw = (cam.width + stride - 1) / stride, gh = (cam.height + stride - 1) / stride;
+    const int64_t pixels = gw * gh;
+    DeviceArray<unsigned long long> stats;
+    cache.pixels = pixels;
+    cache.counts.allocate(static_cast<size_t>(pixels));
+    stats.allocate(3);
+    cache.counts.zero(tracer->stream);
+    stats.zero(tracer->stream);
+    rtd::launchGatherCount(tracer->view, camera, stride, pixels, cache.counts.ptr, stats.ptr, tracer->stream);
+    check(hipGetLastError(), "gather count launch");
+    std::vector<uint32_t> hostCounts(static_cast<size_t>(pixels));
+    check(hipMemcpyAsync(hostCounts.data(), cache.counts.ptr, hostCounts.size() * sizeof(uint32_t),
+                         hipMemcpyDeviceToHost, tracer->stream),
+          "hipMemcpyAsync counts");
+    unsigned long long hostStats[3] = {0, 0, 0};
+    check(hipMemcpyAsync(hostStats, stats.ptr, sizeof(hostStats), hipMemcpyDeviceToHost, tracer->stream),
+          "hipMemcpyAsync stats");
+    check(hipStreamSynchronize(tracer->stream), "hipStreamSynchronize");
+    std::vector<uint64_t> hostOffsets(hostCounts.size());
+    uint64_t total = 0;
+    for (size_t i = 0; i < hostCounts.size(); ++i)
+    {
+        hostOffsets[i] = total;
+        total += hostCounts[i];
+    }
+    cache.offsets.upload(hostOffsets);
+    cache.points.assign(static_cast<size_t>(total), rtd::GatherPoint{});
+    cache.devicePoints.allocate(static_cast<size_t>(total));
+    if (total > 0)
+    {
+        rtd::launchGatherWrite(tracer->view, camera, stride, pixels, cache.counts.ptr, cache.offsets.ptr,
+                               cache.devicePoints.ptr, tracer->stream);
+        check(hipGetLastError(), "gather write launch");
+        check(hipMemcpyAsync(cache.points.data(), cache.devicePoints.ptr, total * sizeof(rtd::GatherPoint),
+                             hipMemcpyDeviceToHost, tracer->stream),
+              "hipMemcpyAsync gather points");
+        check(hipStreamSynchronize(tracer->stream), "hipStreamSynchronize");
+    }
+    for (int k = 0; k < 3; ++k)
+    {
+        cache.stats[k] = hostStats[k];
+    }
+    cache.valid = true;
+    return cache;
 }
 
 template <typename F>
@@ -1018,57 +1084,7 @@ int32_t rt_collect_gather_points(rt_tracer* tracer, int32_t camera, double* rows
         require(camera >= 0 && camera < static_cast<int32_t>(tracer->cameraHost.size()), "camera index out of range");
         require(count != nullptr, "count is null");
         activate(tracer);
-        rt_tracer::GatherCache& cache = tracer->gatherCache[static_cast<size_t>(camera)];
-        if (!cache.valid)
-        {
-            const rtd::Camera& cam = tracer->cameraHost[camera];
-            const int32_t stride = static_cast<int32_t>(std::max<uint64_t>(1, tracer->settings.probe_sub_sample));
-            const int64_t gw = (cam.width + stride - 1) / stride, gh = (cam.height + stride - 1) / stride;
-            const int64_t pixels = gw * gh;
-            DeviceArray<uint32_t> counts;
-            DeviceArray<unsigned long long> stats;
-            DeviceArray<uint64_t> offsets;
-            DeviceArray<rtd::GatherPoint> points;
-            counts.allocate(static_cast<size_t>(pixels));
-            stats.allocate(3);
-            counts.zero(tracer->stream);
-            stats.zero(tracer->stream);
-            rtd::launchGatherCount(tracer->view, camera, stride, pixels, counts.ptr, stats.ptr, tracer->stream);
-            check(hipGetLastError(), "gather count launch");
-            std::vector<uint32_t> hostCounts(static_cast<size_t>(pixels));
-            check(hipMemcpyAsync(hostCounts.data(), counts.ptr, hostCounts.size() * sizeof(uint32_t),
-                                 hipMemcpyDeviceToHost, tracer->stream),
-                  "hipMemcpyAsync counts");
-            unsigned long long hostStats[3] = {0, 0, 0};
-            check(hipMemcpyAsync(hostStats, stats.ptr, sizeof(hostStats), hipMemcpyDeviceToHost, tracer->stream),
-                  "hipMemcpyAsync stats");
-            check(hipStreamSynchronize(tracer->stream), "hipStreamSynchronize");
-            std::vector<uint64_t> hostOffsets(hostCounts.size());
-            uint64_t total = 0;
-            for (size_t i = 0; i < hostCounts.size(); ++i)
-            {
-                hostOffsets[i] = total;
-                total += hostCounts[i];
-            }
-            cache.points.assign(static_cast<size_t>(total), rtd::GatherPoint{});
-            if (total > 0)
-            {
-                offsets.upload(hostOffsets);
-                points.allocate(static_cast<size_t>(total));
-                rtd::launchGatherWrite(tracer->view, camera, stride, pixels, counts.ptr, offsets.ptr, points.ptr,
-                                       tracer->stream);
-                check(hipGetLastError(), "gather write launch");
-                check(hipMemcpyAsync(cache.points.data(), points.ptr, total * sizeof(rtd::GatherPoint),
-                                     hipMemcpyDeviceToHost, tracer->stream),
-                      "hipMemcpyAsync gather points");
-                check(hipStreamSynchronize(tracer->stream), "hipStreamSynchronize");
-            }
-            for (int k = 0; k < 3; ++k)
-            {
-                cache.stats[k] = hostStats[k];
-            }
-            cache.valid = true;
-        }
+        rt_tracer::GatherCache& cache = ensureGatherPoints(tracer, camera);
         *count = cache.points.size();
         if (stats3 != nullptr)
         {
@@ -1096,6 +1112,121 @@ int32_t rt_collect_gather_points(rt_tracer* tracer, int32_t camera, double* rows
                 r[17] = g.sampleTime;
                 r[18] = g.sampleWeight;
             }
+        }
+    });
+}
+
+int32_t rt_store_append(rt_tracer* tracer, const float* records13, uint64_t n)
+{
+    return guarded([&]() {
+        require(tracer != nullptr, "tracer is null");
+        require(n == 0 || records13 != nullptr, "records is null");
+        if (!tracer->probesSet)
+        {
+            throw ApiError(RT_ERR_STATE, "rt_set_probes must be called before rt_store_append");
+        }
+        if (n == 0)
+        {
+            return;
+        }
+        activate(tracer);
+        // BounceStore::append n times (reference src/BounceStore.cpp:11-20): the cursor always
+        // advances, records beyond the capacity are dropped
+        check(hipStreamSynchronize(tracer->stream), "hipStreamSynchronize");
+        unsigned long long cursor = 0;
+        check(hipMemcpy(&cursor, tracer->scalars.ptr + 1, sizeof(cursor), hipMemcpyDeviceToHost), "hipMemcpy cursor");
+        const uint64_t room = cursor < tracer->storeCapacity ? tracer->storeCapacity - cursor : 0;
+        const uint64_t fit = std::min<uint64_t>(room, n);
+        if (fit > 0)
+        {
+            check(hipMemcpy(tracer->storeRecords.ptr + 13 * cursor, records13, fit * 13 * sizeof(float),
+                            hipMemcpyHostToDevice),
+                  "hipMemcpy store append");
+        }
+        cursor += n;
+        check(hipMemcpy(tracer->scalars.ptr + 1, &cursor, sizeof(cursor), hipMemcpyHostToDevice), "hipMemcpy cursor");
+    });
+}
+
+int32_t rt_gather(rt_tracer* tracer, int32_t camera, double gather_cell_size, double min_gather_radius,
+                  uint64_t* stats4)
+{
+    return guarded([&]() {
+        require(tracer != nullptr, "tracer is null");
+        require(camera >= 0 && camera < static_cast<int32_t>(tracer->cameraHost.size()), "camera index out of range");
+        if (!tracer->probesSet)
+        {
+            throw ApiError(RT_ERR_STATE, "rt_set_probes must be called before rt_gather");
+        }
+        activate(tracer);
+        rt_tracer::GatherCache& cache = ensureGatherPoints(tracer, camera);
+        check(hipStreamSynchronize(tracer->stream), "hipStreamSynchronize");
+        unsigned long long cursor = 0;
+        check(hipMemcpy(&cursor, tracer->scalars.ptr + 1, sizeof(cursor), hipMemcpyDeviceToHost), "hipMemcpy cursor");
+        const uint64_t n = std::min<uint64_t>(cursor, tracer->storeCapacity);
+        require(n < (1ull << 31), "bounce store too large for the gather index");
+        const double cellSize = gather_cell_size > 0.0 ? gather_cell_size : 1.0;  // reference src/BounceStore.cpp:44
+
+        // index: key every record by its cell, sort (key, record) pairs
+        DeviceArray<unsigned long long> keysIn, keysOut, stats;
+        DeviceArray<uint32_t> orderIn, orderOut;
+        DeviceArray<unsigned char> scratch;
+        uint64_t indexed = 0;
+        if (n > 0)
+        {
+            keysIn.allocate(n);
+            keysOut.allocate(n);
+            orderIn.allocate(n);
+            orderOut.allocate(n);
+            rtd::launchStoreKeys(tracer->storeRecords.ptr, n, 1.0 / cellSize, keysIn.ptr, orderIn.ptr, tracer->stream);
+            check(hipGetLastError(), "store keys launch");
+            const size_t bytes =
+                rtd::sortStoreKeys(nullptr, 0, keysIn.ptr, keysOut.ptr, orderIn.ptr, orderOut.ptr, n, tracer->stream);
+            scratch.allocate(bytes > 0 ? bytes : 1);
+            rtd::sortStoreKeys(scratch.ptr, bytes, keysIn.ptr, keysOut.ptr, orderIn.ptr, orderOut.ptr, n, tracer->stream);
+            check(hipGetLastError(), "store sort");
+            // records whose cell could not be packed sort to the end; find where they start
+            std::vector<unsigned long long> hostKeys(n);
+            check(hipMemcpyAsync(hostKeys.data(), keysOut.ptr, n * sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                                 tracer->stream),
+                  "hipMemcpyAsync keys");
+            check(hipStreamSynchronize(tracer->stream), "hipStreamSynchronize");
+            indexed = static_cast<uint64_t>(
+                std::lower_bound(hostKeys.begin(), hostKeys.end(), rtd::kEmptyKey) - hostKeys.begin());
+        }
+        stats.allocate(2);
+        stats.zero(tracer->stream);
+
+        rtd::GatherArgs args{};
+        args.scene = tracer->view;
+        args.store = tracer->storeRecords.ptr;
+        args.keys = keysOut.ptr;
+        args.order = orderOut.ptr;
+        args.indexed = indexed;
+        args.invCellSize = 1.0 / cellSize;
+        args.minGatherRadius = min_gather_radius;
+        args.timeHalfWindow = std::max(0.0f, static_cast<float>(tracer->settings.shutter_time));
+        args.camera = camera;
+        args.pixels = cache.pixels;
+        args.counts = cache.counts.ptr;
+        args.offsets = cache.offsets.ptr;
+        args.points = cache.devicePoints.ptr;
+        args.stats = stats.ptr;
+        if (!cache.points.empty())
+        {
+            rtd::launchGather(args, tracer->stream);
+            check(hipGetLastError(), "gather launch");
+        }
+        unsigned long long hostStats[2] = {0, 0};
+        check(hipMemcpyAsync(hostStats, stats.ptr, sizeof(hostStats), hipMemcpyDeviceToHost, tracer->stream),
+              "hipMemcpyAsync gather stats");
+        check(hipStreamSynchronize(tracer->stream), "hipStreamSynchronize");
+        if (stats4 != nullptr)
+        {
+            stats4[0] = cache.points.size();  // pixelsHit: every record reached a non-delta surface
+            stats4[1] = hostStats[0];
+            stats4[2] = hostStats[1];
+            stats4[3] = n - indexed;
         }
     });
 }

@@ -195,6 +195,7 @@ struct SceneView
     int32_t patchCount;
     int32_t stackDepth;  // traversal stack entries per lane (deepest tree + 1)
     int32_t volumeCount, lightCount, cameraCount, bounceThreshold;
+    int32_t materialCount, pad1;
     double terminationThreshold;
     double splatLuminanceClamp;
     uint64_t photonsPerLight;

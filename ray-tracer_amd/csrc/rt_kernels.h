@@ -102,6 +102,32 @@ void launchGatherCount(const SceneView& scene, int32_t camera, int32_t stride, i
                        unsigned long long* stats, hipStream_t stream);
 void launchGatherWrite(const SceneView& scene, int32_t camera, int32_t stride, int64_t pixels, const uint32_t* counts,
                        const uint64_t* offsets, GatherPoint* out, hipStream_t stream);
+// The gather (ProbeGather::run) over the bounce store of the last pass.
+struct GatherArgs
+{
+    SceneView scene;
+    const float* store;                 // [records][13]
+    const unsigned long long* keys;     // packed cell of each record, ascending
+    const uint32_t* order;              // record index, same order as keys
+    uint64_t indexed;                   // records that carry a valid key
+    double invCellSize;
+    double minGatherRadius;
+    float timeHalfWindow;
+    int32_t camera;
+    int64_t pixels;                     // sampled pixels of the camera's probe pass
+    const uint32_t* counts;             // gather points per sampled pixel
+    const uint64_t* offsets;            // first gather point of each sampled pixel
+    const GatherPoint* points;
+    unsigned long long* stats;          // [0] contributions added, [1] deposits summed
+};
+void launchStoreKeys(const float* store, uint64_t n, double invCellSize, unsigned long long* keys, uint32_t* order,
+                     hipStream_t stream);
+// Stable ascending sort of (keys, order); returns the byte size of the scratch it needs when
+// `scratch` is null.
+size_t sortStoreKeys(void* scratch, size_t scratchBytes, const unsigned long long* keysIn,
+                     unsigned long long* keysOut, const uint32_t* orderIn, uint32_t* orderOut, uint64_t n,
+                     hipStream_t stream);
+void launchGather(const GatherArgs& args, hipStream_t stream);
 void launchProbeTest(const ProbeView& probes, int64_t n, const double* points, uint8_t* out, hipStream_t stream);
 
 }  // namespace rtd

@@ -15,6 +15,8 @@
 
 #include <cstdio>
 
+#include <hipcub/hipcub.hpp>
+
 namespace rtd
 {
 
@@ -826,6 +828,225 @@ __global__ void probeTestKernel(const ProbeView pv, int64_t n, const double* poi
     out[i] = anyProbeWithin(pv, mk(points[3 * i], points[3 * i + 1], points[3 * i + 2])) ? 1 : 0;
 }
 
+// ---------------------------------------------------------------- the gather
+// BounceStore::buildIndex (reference src/BounceStore.cpp:42-53) keys every record by the
+// cell of its float position; here the key packs the three cell coordinates, z in the
+// high bits, so that ascending key order IS the dz / dy / dx order in which
+// BounceStore::radiusSearch (:55-98) walks the cells, and a stable sort keeps the records
+// of one cell in store order.  A record whose cell does not fit 21 bits per axis gets
+// kEmptyKey and is left out of the index.
+RT_DEV unsigned long long packCell(int64_t x, int64_t y, int64_t z)
+{
+    return (static_cast<unsigned long long>(z + kPackLimit) << 42) | (static_cast<unsigned long long>(y + kPackLimit) << 21) |
+           static_cast<unsigned long long>(x + kPackLimit);
+}
+
+__global__ void storeKeysKernel(const float* store, uint64_t n, double invCellSize, unsigned long long* keys,
+                                uint32_t* order)
+{
+    const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* r = store + 13 * i;
+    const int64_t x = static_cast<int64_t>(__builtin_floor(static_cast<double>(r[0]) * invCellSize));
+    const int64_t y = static_cast<int64_t>(__builtin_floor(static_cast<double>(r[1]) * invCellSize));
+    const int64_t z = static_cast<int64_t>(__builtin_floor(static_cast<double>(r[2]) * invCellSize));
+    const bool fits = x >= -kPackLimit && x < kPackLimit && y >= -kPackLimit && y < kPackLimit && z >= -kPackLimit &&
+                      z < kPackLimit;
+    keys[i] = fits ? packCell(x, y, z) : kEmptyKey;
+    order[i] = static_cast<uint32_t>(i);
+}
+
+RT_DEV uint64_t lowerBound(const unsigned long long* keys, uint64_t n, unsigned long long key)
+{
+    uint64_t lo = 0, hi = n;
+    while (lo < hi)
+    {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (keys[mid] < key) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+
+RT_DEV int64_t clampCell(int64_t v) { return v < -kPackLimit ? -kPackLimit : (v > kPackLimit - 1 ? kPackLimit - 1 : v); }
+
+// testing::gatherRadiance, reference src/ProbeGather.cpp:596-728, for one gather point.
+RT_DEV Color gatherRadiance(const GatherArgs& a, const GatherPoint& gp, unsigned long long* deposits)
+{
+    const Color black{0.0f, 0.0f, 0.0f};
+    const bool isEmitter = gp.material < 0;
+    const Vec wo = mk(gp.viewDir[0], gp.viewDir[1], gp.viewDir[2]);
+    const Vec normal = mk(gp.normal[0], gp.normal[1], gp.normal[2]);
+    const Vec position = mk(gp.position[0], gp.position[1], gp.position[2]);
+    if (dot(wo, normal) <= 0.0)
+    {
+        return black;
+    }
+    const double r = (a.minGatherRadius > 0.0 && gp.footprintRadius < a.minGatherRadius) ? a.minGatherRadius
+                                                                                         : gp.footprintRadius;
+    if (r <= 0.0 || a.indexed == 0)
+    {
+        return black;
+    }
+    const double r2 = r * r;
+    const double planeBand = 2.0 * r;
+    const int64_t cx = static_cast<int64_t>(__builtin_floor(position.x * a.invCellSize));
+    const int64_t cy = static_cast<int64_t>(__builtin_floor(position.y * a.invCellSize));
+    const int64_t cz = static_cast<int64_t>(__builtin_floor(position.z * a.invCellSize));
+    const int64_t reach = static_cast<int64_t>(__builtin_ceil(r * a.invCellSize));
+    // the cube of cells, cut to the range that records can occupy
+    const int64_t x0 = clampCell(cx - reach), x1 = clampCell(cx + reach);
+    const int64_t y0 = clampCell(cy - reach), y1 = clampCell(cy + reach);
+    const int64_t z0 = clampCell(cz - reach), z1 = clampCell(cz + reach);
+    if (cx + reach < -kPackLimit || cx - reach >= kPackLimit || cy + reach < -kPackLimit || cy - reach >= kPackLimit ||
+        cz + reach < -kPackLimit || cz - reach >= kPackLimit)
+    {
+        return black;
+    }
+    const Material* material = isEmitter ? nullptr : &a.scene.materials[gp.material];
+    Color sum = black;
+    unsigned long long kept = 0;
+    // rows of cells along x are contiguous in key order; when the cube is wide, whole z
+    // slabs are scanned and filtered instead of searching every row
+    const bool bySlab = (y1 - y0) > 16;
+    for (int64_t z = z0; z <= z1; ++z)
+    {
+        for (int64_t y = y0; y <= y1; ++y)
+        {
+            const unsigned long long first = packCell(x0, y, z);
+            const unsigned long long last = bySlab ? packCell(x1, y1, z) : packCell(x1, y, z);
+            for (uint64_t j = lowerBound(a.keys, a.indexed, first); j < a.indexed; ++j)
+            {
+                const unsigned long long key = a.keys[j];
+                if (key > last)
+                {
+                    break;
+                }
+                if (bySlab)
+                {
+                    const int64_t kx = static_cast<int64_t>(key & ((1ull << 21) - 1)) - kPackLimit;
+                    if (kx < x0 || kx > x1)
+                    {
+                        continue;
+                    }
+                }
+                const float* rec = a.store + 13ull * a.order[j];
+                const double ddx = static_cast<double>(rec[0]) - position.x;
+                const double ddy = static_cast<double>(rec[1]) - position.y;
+                const double ddz = static_cast<double>(rec[2]) - position.z;
+                if (!(ddx * ddx + ddy * ddy + ddz * ddz <= r2))
+                {
+                    continue;
+                }
+                const float time = rec[9];
+                if (!__builtin_isinf(time) || time < 0.0f)  // +inf marks a timeless (emitter) deposit
+                {
+                    if (__builtin_fabsf(time - gp.sampleTime) > a.timeHalfWindow)
+                    {
+                        continue;
+                    }
+                }
+                const Vec dn = mk(rec[6], rec[7], rec[8]);
+                const Color power{rec[10], rec[11], rec[12]};
+                if (isEmitter)
+                {
+                    if (dot(dn, normal) < 0.5)
+                    {
+                        continue;
+                    }
+                    sum.r += power.r;
+                    sum.g += power.g;
+                    sum.b += power.b;
+                    kept += 1;
+                    continue;
+                }
+                const double dnLen = magnitude(dn);
+                if (dnLen > 1e-4)
+                {
+                    if (dot(dn / dnLen, normal) < 0.5)
+                    {
+                        continue;
+                    }
+                }
+                const double planeDist = dabs(dot(mk(rec[0], rec[1], rec[2]) - position, normal));
+                if (planeDist > planeBand)
+                {
+                    continue;
+                }
+                const Vec wi = neg(mk(rec[3], rec[4], rec[5]));
+                const Color f = evaluateMaterial(*material, wi, wo, normal);
+                const Color fp = f * power;
+                sum.r += fp.r;
+                sum.g += fp.g;
+                sum.b += fp.b;
+                kept += 1;
+            }
+            if (bySlab)
+            {
+                break;  // the slab scan covered every row of this z
+            }
+        }
+    }
+    *deposits = kept;
+    if (kept == 0)
+    {
+        return black;
+    }
+    const double area = kPi * r * r;
+    const float scale = static_cast<float>((4.0 / kPi) / area);
+    return sum * scale;
+}
+
+// ProbeGather::run / gatherRecords, reference src/ProbeGather.cpp:865-994: one thread per
+// sampled pixel adds that pixel's records in their order, as the reference's single-threaded
+// loop does, then lands the sum in the camera buffer (Buffer::addColor, src/Buffer.cpp:22-37).
+__global__ __launch_bounds__(256) void gatherKernel(const GatherArgs a)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    unsigned long long added = 0, depositsAccum = 0;
+    if (i < a.pixels && a.counts[i] != 0)
+    {
+        const Camera& cam = a.scene.cameras[a.camera];
+        const GatherPoint* points = a.points + a.offsets[i];
+        Color acc{0.0f, 0.0f, 0.0f};
+        for (uint32_t k = 0; k < a.counts[i]; ++k)
+        {
+            const GatherPoint& gp = points[k];
+            if (gp.material >= a.scene.materialCount)
+            {
+                continue;
+            }
+            unsigned long long deposits = 0;
+            const Color radiance = gatherRadiance(a, gp, &deposits);
+            const Color throughput{gp.throughput[0], gp.throughput[1], gp.throughput[2]};
+            const Color contribution = throughput * radiance * gp.sampleWeight;
+            depositsAccum += deposits;
+            if (contribution.r == 0.0f && contribution.g == 0.0f && contribution.b == 0.0f)
+            {
+                continue;
+            }
+            acc.r += contribution.r;
+            acc.g += contribution.g;
+            acc.b += contribution.b;
+            added += 1;
+        }
+        const uint64_t w = static_cast<uint64_t>(cam.width), h = static_cast<uint64_t>(cam.height);
+        const uint64_t at = ((static_cast<uint64_t>(points[0].py) * w) + static_cast<uint64_t>(points[0].px)) * 3;
+        if (added != 0 && at + 2 < w * h * 3)
+        {
+            atomicAdd(cam.buffer + at + 0, acc.r);
+            atomicAdd(cam.buffer + at + 1, acc.g);
+            atomicAdd(cam.buffer + at + 2, acc.b);
+        }
+    }
+    const unsigned long long totals[2] = {waveSum(added), waveSum(depositsAccum)};
+    if ((threadIdx.x & 63) == 0)
+    {
+        if (totals[0] != 0) atomicAdd(a.stats + 0, totals[0]);
+        if (totals[1] != 0) atomicAdd(a.stats + 1, totals[1]);
+    }
+}
+
 int gridFor(int64_t n) { return static_cast<int>((n + 255) / 256); }
 
 // dynamic LDS of a kernel that casts rays: one traversal stack per lane
@@ -930,6 +1151,31 @@ void launchGatherWrite(const SceneView& scene, int32_t camera, int32_t stride, i
     if (pixels <= 0) return;
     hipLaunchKernelGGL(gatherWriteKernel, dim3(gridFor(pixels)), dim3(256), stackBytes(scene, 256), stream, scene, camera, stride, counts,
                        offsets, out);
+}
+
+void launchStoreKeys(const float* store, uint64_t n, double invCellSize, unsigned long long* keys, uint32_t* order,
+                     hipStream_t stream)
+{
+    if (n == 0) return;
+    hipLaunchKernelGGL(storeKeysKernel, dim3(gridFor(static_cast<int64_t>(n))), dim3(256), 0, stream, store, n,
+                       invCellSize, keys, order);
+}
+
+size_t sortStoreKeys(void* scratch, size_t scratchBytes, const unsigned long long* keysIn,
+                     unsigned long long* keysOut, const uint32_t* orderIn, uint32_t* orderOut, uint64_t n,
+                     hipStream_t stream)
+{
+    size_t bytes = scratchBytes;
+    // radix sort is stable: records of one cell keep their store order
+    (void)hipcub::DeviceRadixSort::SortPairs(scratch, bytes, keysIn, keysOut, orderIn, orderOut, static_cast<int>(n), 0,
+                                             64, stream);
+    return bytes;
+}
+
+void launchGather(const GatherArgs& args, hipStream_t stream)
+{
+    if (args.pixels <= 0) return;
+    hipLaunchKernelGGL(gatherKernel, dim3(gridFor(args.pixels)), dim3(256), 0, stream, args);
 }
 
 void launchProbeTest(const ProbeView& probes, int64_t n, const double* points, uint8_t* out, hipStream_t stream)

@@ -53,6 +53,8 @@ _SIGNATURES = {
                                     C.c_void_p, C.c_void_p]),
     "rt_collect_gather_points": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64),
                                              C.c_void_p]),
+    "rt_store_append": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64]),
+    "rt_gather": (C.c_int32, [C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_void_p]),
     "rt_probe_keep_test": (C.c_int32, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "rt_cast_rays": (C.c_int32, [C.c_void_p, C.c_int64, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]),
     "rt_emit": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
@@ -240,6 +242,16 @@ class Tracer:
                 continue
             parts.append(self.collect_gather_points(c)[0][:, 2:5])
         return np.ascontiguousarray(np.concatenate(parts, axis=0))
+
+    def store_append(self, records):
+        records = np.ascontiguousarray(records, dtype=np.float32).reshape(-1, 13)
+        _check(tracer_lib().rt_store_append(self._handle, _ptr(records), records.shape[0]))
+
+    def gather(self, camera, gather_cell_size, min_gather_radius):
+        """Index the store and add the camera's gathered radiance into its buffer; returns the stats."""
+        stats = np.zeros(4, dtype=np.uint64)
+        _check(tracer_lib().rt_gather(self._handle, camera, gather_cell_size, min_gather_radius, _ptr(stats)))
+        return dict(zip(("pixels_hit", "pixels_gathered", "deposits_accum", "unindexed"), (int(v) for v in stats)))
 
     def probe_keep_test(self, points):
         points = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)

@@ -239,6 +239,62 @@ def test_probe_keep_test_matches_store_decisions(rt, scene_opener):
     assert np.array_equal(tracer.probe_keep_test(points), got)
 
 
+GATHER_SCENES = {
+    "mixed": {"scene": "tests/scenes/mixed.json", "photons_per_light": 2500},
+    "mixed_tight": {"scene": "tests/scenes/mixed.json", "photons_per_light": 2500, "probe_keep_radius_scale": 2.0},
+    "cbgmd": {"scene": "scenes/CornellBoxGlassMirrorDiffuse.json", "photons_per_light": 60000, "image": 96, "seed": 3},
+    "bombardment": {"scene": "scenes/MirrorBombardment-200M.json", "photons_per_light": 400000, "image": 128,
+                    "seed": 11},
+}
+
+
+@pytest.mark.parametrize("name", sorted(GATHER_SCENES))
+def test_gather_equals_oracle(rt, scene_opener, name):
+    """The whole probe-mode frame after the photon pass.  (1) Given the SAME store, record for
+    record in the same order, the device gather (sort by cell, one thread per pixel) returns
+    the oracle's camera buffers bit for bit.  (2) The device's own frame (emitter deposits
+    pre-loaded, photon pass, gather) holds the same store as a multiset and the same image up
+    to the rounding of a different float summation order (the reference's own result depends
+    on append order the same way when it runs more than one worker)."""
+    scene, tracer, orc = _open(rt, scene_opener, GATHER_SCENES[name])
+    setup = O.frame_setup(orc, O.RNG_COUNTER, O.MATH_PORTABLE)
+    keep = setup["keep_radius"]
+    emitters, _ = orc.deposit_emitters(setup["probes"], keep, keep, setup["emitter_spacing"])
+    ref = orc.trace(rng_mode=O.RNG_COUNTER, math_mode=O.MATH_PORTABLE, sink_mode=O.SINK_PROBE, threads=1,
+                    probes=setup["probes"], probe_cell_size=keep, keep_radius=keep,
+                    store_capacity=setup["store_capacity"], preload=emitters)
+    assert ref["store_size"] > len(emitters)
+    cameras = [c for c in range(scene.desc.camera_count)
+               if scene.desc.cameras[c].bounce_filter < 0 and scene.desc.cameras[c].light_filter < 0]
+    want = {c: orc.gather(c, ref["store"], setup["gather_cell"], setup["min_gather_radius"]) for c in cameras}
+
+    tracer.set_probes(tracer.collect_probe_positions(), keep, keep, setup["store_capacity"])
+    # (1) same store, same order
+    tracer.reset()
+    tracer.store_append(ref["store"])
+    for c in cameras:
+        stats = tracer.gather(c, setup["gather_cell"], setup["min_gather_radius"])
+        buffer, ostats = want[c]
+        assert stats["unindexed"] == 0
+        assert (stats["pixels_hit"], stats["pixels_gathered"], stats["deposits_accum"]) == (
+            ostats["pixels_hit"], ostats["pixels_gathered"], ostats["deposits_accum"])
+        assert ostats["pixels_gathered"] > 0
+        assert_bits_equal(tracer.camera_buffer(c), buffer, f"{name} camera {c} gathered buffer")
+    # (2) the device's own frame
+    tracer.reset()
+    tracer.store_append(emitters)
+    tracer.trace(sink_mode=1)
+    counters = tracer.counters()
+    assert counters["store_size"] == ref["store_size"] and counters["kept"] == ref["kept"]
+    assert_bits_equal(_sorted_records(tracer.store()), _sorted_records(ref["store"]), "store records")
+    for c in cameras:
+        stats = tracer.gather(c, setup["gather_cell"], setup["min_gather_radius"])
+        buffer, ostats = want[c]
+        assert stats["deposits_accum"] == ostats["deposits_accum"]
+        got = tracer.camera_buffer(c)
+        np.testing.assert_allclose(got, buffer, rtol=2e-4, atol=1e-6 * float(np.abs(buffer).max()))
+
+
 @pytest.mark.parametrize("name", ["mixed", "multicam", "cbgmd"])
 def test_splat_sink_equals_oracle(rt, scene_opener, name):
     """Sink B: direct camera splat (+ density grid).  Buffers are float-atomic sums, so they
