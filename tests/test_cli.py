@@ -1,0 +1,114 @@
+"""The command line (`ray-tracer <scene.json>`, reference src/main.cpp:22-154) end to end on
+the GPU: scene JSON -> C++ loader -> C-ABI photon pass and gather -> tonemap -> PNG16."""
+import json
+import os
+import struct
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from conftest import REPO
+
+CLI = os.path.join(REPO, "ray-tracer_amd", "host", "ray-tracer")
+
+
+def read_png16(path):
+    data = open(path, "rb").read()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    at, idat, header, texts = 8, b"", None, {}
+    while at < len(data):
+        (n,), kind = struct.unpack(">I", data[at:at + 4]), data[at + 4:at + 8]
+        body = data[at + 8:at + 8 + n]
+        (crc,) = struct.unpack(">I", data[at + 8 + n:at + 12 + n])
+        assert crc == zlib.crc32(kind + body), kind
+        if kind == b"IHDR":
+            header = struct.unpack(">IIBBBBB", body)
+        elif kind == b"IDAT":
+            idat += body
+        elif kind == b"tEXt":
+            key, _, value = body.partition(b"\0")
+            texts[key.decode()] = value.decode()
+        at += 12 + n
+    w, h, depth, colour, _, _, interlace = header
+    assert (depth, colour, interlace) == (16, 2, 0)
+    raw = np.frombuffer(zlib.decompress(idat), dtype=np.uint8).reshape(h, 1 + w * 6)
+    assert (raw[:, 0] == 0).all()
+    return raw[:, 1:].copy().view(">u2").reshape(h, w, 3).astype(np.uint16), texts
+
+
+def run_cli(*args, env=None):
+    return subprocess.run([CLI, *args], capture_output=True, text=True, timeout=300, env=env)
+
+
+def test_cli_argument_errors_exit_1(tmp_path):
+    assert os.path.exists(CLI), "build the CLI with __graft_entry__.build()"
+    assert run_cli().returncode == 1
+    assert run_cli("a.json", "b.json").returncode == 1
+    r = run_cli(str(tmp_path / "missing.json"))
+    assert r.returncode == 1 and "Provided path is invalid" in r.stdout
+    bad = tmp_path / "bad.json"
+    bad.write_text("{ this is not json")
+    r = run_cli(str(bad))
+    assert r.returncode == 1 and "ERROR:" in r.stdout
+    # a scene that names an unknown material fails in the loader, before any GPU work
+    scene = json.load(open(os.path.join(REPO, "tests", "scenes", "furnace.json")))
+    scene["$scene"]["Box"]["BackZ"]["$material"] = "NoSuchMaterial"
+    broken = tmp_path / "broken.json"
+    broken.write_text(json.dumps(scene))
+    r = run_cli(str(broken))
+    assert r.returncode == 1 and "ERROR:" in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("probe_gather", [True, False])
+def test_cli_renders_frame_equal_to_oracle(rt, tmp_path, probe_gather):
+    scene = json.load(open(os.path.join(REPO, "tests", "scenes", "mixed.json")))
+    cfg = scene["$renderConfiguration"]
+    cfg.update({"$photonsPerLight": 3000, "$renderPath": str(tmp_path / "out"), "$renderName": "mixed",
+                "$probeGather": probe_gather, "$probeKeepRadiusScale": 2.0})
+    path = tmp_path / "scene.json"
+    path.write_text(json.dumps(scene))
+    env = dict(os.environ, RT_DUMP_BUFFERS=str(tmp_path / "dump"))
+    r = run_cli(str(path), env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "Goodbye!" in r.stdout
+    image, texts = read_png16(tmp_path / "out" / "mixed.0.png")
+    assert texts.get("Title") == "mixed"
+
+    # the same frame from the oracle (counter draws, portable math)
+    loaded = rt.Scene(str(path))
+    orc = O.Oracle(loaded)
+    desc = loaded.desc
+    if probe_gather:
+        setup = O.frame_setup(orc, O.RNG_COUNTER, O.MATH_PORTABLE)
+        keep = setup["keep_radius"]
+        emitters, _ = orc.deposit_emitters(setup["probes"], keep, keep, setup["emitter_spacing"])
+        ref = orc.trace(rng_mode=O.RNG_COUNTER, math_mode=O.MATH_PORTABLE, sink_mode=O.SINK_PROBE, threads=4,
+                        probes=setup["probes"], probe_cell_size=keep, keep_radius=keep,
+                        store_capacity=setup["store_capacity"], preload=emitters)
+        buffers = []
+        for c in range(desc.camera_count):
+            cam = desc.cameras[c]
+            if cam.bounce_filter >= 0 or cam.light_filter >= 0:
+                buffers.append(np.zeros((cam.height, cam.width, 3), dtype=np.float32))
+            else:
+                buffers.append(orc.gather(c, ref["store"], setup["gather_cell"], setup["min_gather_radius"])[0])
+    else:
+        d = orc.derive()
+        ref = orc.trace(rng_mode=O.RNG_COUNTER, math_mode=O.MATH_PORTABLE, sink_mode=O.SINK_SPLAT, threads=4,
+                        min_splat_radius=d["min_splat_radius"], density_cell_size=d["cell_size"])
+        buffers = ref["splat"]
+    for c, want in enumerate(buffers):
+        cam = desc.cameras[c]
+        got = np.fromfile(tmp_path / "dump" / f"camera{c}.f32", dtype=np.float32).reshape(cam.height, cam.width, 3)
+        assert np.abs(want).max() > 0
+        # float sums in a different order: tolerance stated relative to the brightest pixel
+        np.testing.assert_allclose(got, want, rtol=2e-4, atol=1e-6 * float(np.abs(want).max()))
+        if c == 0:
+            # the PNG holds exactly the reference tonemap of the buffer the CLI produced
+            iso, shutter, f_number = cam.iso, cam.shutter_time, cam.f_number
+            saturation = (f_number * f_number * 12.5) / (shutter * iso) if shutter * iso > 0 else 0.0
+            assert np.array_equal(image, O.tonemap(got, saturation))
