@@ -34,8 +34,18 @@ __device__ unsigned long long g_rtDiag[16];
             atomicAdd(&g_rtDiag[(slot) + 1], static_cast<unsigned long long>(__builtin_popcountll(diagMask))); \
         }                                                                                      \
     } while (0)
+// cycles spent by a wave between RT_DIAG_TIC and RT_DIAG_TOC, summed into g_rtDiag[slot]
+#define RT_DIAG_TIC const long long diagStart = __builtin_readcyclecounter()
+#define RT_DIAG_TOC(slot)                                                                       \
+    do                                                                                          \
+    {                                                                                           \
+        const long long diagCycles = __builtin_readcyclecounter() - diagStart;                 \
+        if ((threadIdx.x & 63) == 0) atomicAdd(&g_rtDiag[slot], static_cast<unsigned long long>(diagCycles)); \
+    } while (0)
 #else
 #define RT_DIAG_TRIP(slot) do { } while (0)
+#define RT_DIAG_TIC do { } while (0)
+#define RT_DIAG_TOC(slot) do { } while (0)
 #endif
 
 namespace rtd
@@ -195,7 +205,7 @@ struct SceneView
     int32_t patchCount;
     int32_t stackDepth;  // traversal stack entries per lane (deepest tree + 1)
     int32_t volumeCount, lightCount, cameraCount, bounceThreshold;
-    int32_t materialCount, pad1;
+    int32_t materialCount, meshVolumeCount;
     double terminationThreshold;
     double splatLuminanceClamp;
     uint64_t photonsPerLight;

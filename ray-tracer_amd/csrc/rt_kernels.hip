@@ -24,7 +24,11 @@ namespace
 {
 
 constexpr int kTraceThreads = 256;
-constexpr unsigned long long kChunk = 1024;  // photon ids a wave claims per atomic
+constexpr unsigned long long kChunk = 2048;  // photon ids a wave claims per atomic
+// Emission-order sort of a chunk (see sortChunk): grid cells per axis and the LDS a wave
+// needs for it: sorted ids (u16) + keys (u16) + cell counters (u32).
+constexpr int kSortAxis = 32, kSortCells = kSortAxis * kSortAxis;
+constexpr int kSortBytesPerWave = static_cast<int>(kChunk) * 2 + static_cast<int>(kChunk) * 2 + kSortCells * 4;
 constexpr double kSelfHitThreshold = 1e-4;   // reference src/Worker.cpp:36
 
 RT_DEV unsigned lanesBelow(unsigned long long mask)
@@ -337,6 +341,90 @@ RT_DEV void splatToCamera(const TraceArgs& a, const Vec& incoming, const Color& 
     }
 }
 
+// A wave's chunk of photon ids is traced in EMISSION ORDER rather than id order: the ids
+// are bucketed by the cell of a kSortAxis x kSortAxis grid over the two uniform draws
+// that steer the photon's initial direction (cells in Morton order), so that the 64
+// photons a wave holds at any time leave the light in nearly the same direction, walk
+// nearly the same nodes and finish their casts together.  A photon's path depends only
+// on its id (the counter-based draws), so the order changes nothing but the schedule.
+// `area` is this wave's sort scratch in LDS; on return sorted[0 .. count) holds the
+// chunk-relative ids.
+RT_DEV uint32_t spreadBits5(uint32_t v)  // 5 bits -> every other bit
+{
+    v = (v | (v << 4)) & 0x0F0Fu;
+    v = (v | (v << 2)) & 0x3333u;
+    v = (v | (v << 1)) & 0x5555u;
+    return v;
+}
+
+RT_DEV void sortChunk(const TraceArgs& a, unsigned long long chunkBase, uint32_t count, unsigned char* area, Rng& rng)
+{
+    const int lane = threadIdx.x & 63;
+    unsigned short* sorted = reinterpret_cast<unsigned short*>(area);
+    unsigned short* keys = sorted + kChunk;
+    uint32_t* cells = reinterpret_cast<uint32_t*>(keys + kChunk);
+    for (int c = lane; c < kSortCells; c += 64)
+    {
+        cells[c] = 0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t j = lane; j < count; j += 64)
+    {
+        const unsigned long long id = chunkBase + j;
+        const int lightId = static_cast<int>(id / a.photonCount);
+        const unsigned long long photonIndex = a.firstPhoton + id % a.photonCount;
+        rng.begin(static_cast<uint32_t>(lightId), photonIndex, RT_STAGE_EMIT);
+        double u0 = rng.value(), u1 = rng.value();
+        if (a.scene.lights[lightId].type == RT_LIGHT_AREA)
+        {
+            // an area light draws its origin first; the direction comes from draws 3 and 4
+            u0 = rng.value();
+            u1 = rng.value();
+        }
+        const uint32_t cx = static_cast<uint32_t>(u0 * kSortAxis) & (kSortAxis - 1);
+        const uint32_t cy = static_cast<uint32_t>(u1 * kSortAxis) & (kSortAxis - 1);
+        const uint32_t key = spreadBits5(cx) | (spreadBits5(cy) << 1);
+        keys[j] = static_cast<unsigned short>(key);
+        atomicAdd(&cells[key], 1u);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // exclusive prefix sum of the cell counts: 16 consecutive cells per lane, then across lanes
+    constexpr int kPerLane = kSortCells / 64;
+    uint32_t local[kPerLane];
+    uint32_t sum = 0;
+#pragma unroll
+    for (int k = 0; k < kPerLane; ++k)
+    {
+        local[k] = cells[lane * kPerLane + k];
+        sum += local[k];
+    }
+    uint32_t scan = sum;
+#pragma unroll
+    for (int offset = 1; offset < 64; offset <<= 1)
+    {
+        const uint32_t other = __shfl_up(scan, offset, 64);
+        if (lane >= offset) scan += other;
+    }
+    uint32_t running = scan - sum;
+#pragma unroll
+    for (int k = 0; k < kPerLane; ++k)
+    {
+        cells[lane * kPerLane + k] = running;
+        running += local[k];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t j = lane; j < count; j += 64)
+    {
+        const uint32_t at = atomicAdd(&cells[keys[j]], 1u);
+        sorted[at] = static_cast<unsigned short>(j);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // Sink selects the deposit path and Record the per-photon path dump at compile time, so
 // that the probe-sink kernel carries neither the splat's shadow-ray cast nor the dump.
 template <int Sink, bool Record>
@@ -345,8 +433,14 @@ __global__ __launch_bounds__(kTraceThreads) void traceKernel(const TraceArgs a)
     const SceneView& s = a.scene;
     const int lane = threadIdx.x & 63;
 
-    // wave-uniform claim of photon ids
-    unsigned long long chunkNext = 0, chunkEnd = 0;
+    // this wave's chunk of photon ids, in emission order (LDS)
+    extern __shared__ unsigned long long rtTraversalStack[];
+    unsigned char* sortArea = reinterpret_cast<unsigned char*>(rtTraversalStack + static_cast<size_t>(s.stackDepth) * kTraceThreads) +
+                              static_cast<size_t>(threadIdx.x >> 6) * kSortBytesPerWave;
+    const unsigned short* sortedIds = reinterpret_cast<const unsigned short*>(sortArea);
+    unsigned long long chunkBase = 0;     // wave-uniform
+    uint32_t chunkNext = 0, chunkCount = 0;
+    bool exhausted = false;               // the global id range is used up (wave-uniform)
 
     bool alive = false, finished = false;
     Ray ray;
@@ -367,34 +461,47 @@ __global__ __launch_bounds__(kTraceThreads) void traceKernel(const TraceArgs a)
     while (true)
     {
         // ---- refill idle lanes (Worker::processLights + Light::emit) ----
-        const bool need = !alive && !finished;
-        const unsigned long long needMask = __ballot(need);
-        if (needMask != 0)
+        // two passes: when the current chunk runs out in the middle of a refill, the rest of
+        // the lanes are served from the next chunk
+#pragma unroll 1
+        for (int pass = 0; pass < 2; ++pass)
         {
-            const unsigned long long n = static_cast<unsigned long long>(__builtin_popcountll(needMask));
-            const unsigned long long rank = lanesBelow(needMask);
-            const unsigned long long avail = chunkEnd - chunkNext;
-            unsigned long long id;
-            if (n > avail)
+            const bool need = !alive && !finished;
+            const unsigned long long needMask = __ballot(need);
+            if (needMask == 0)
+            {
+                break;
+            }
+            if (chunkNext >= chunkCount && !exhausted)
             {
                 unsigned long long fresh = 0;
-                if (lane == __builtin_ctzll(needMask))
+                if (lane == 0)
                 {
                     fresh = atomicAdd(a.workCounter, kChunk);
                 }
-                fresh = __shfl(fresh, __builtin_ctzll(needMask), 64);
-                id = rank < avail ? chunkNext + rank : fresh + (rank - avail);
-                chunkNext = fresh + (n - avail);
-                chunkEnd = fresh + kChunk;
+                chunkBase = __shfl(fresh, 0, 64);
+                chunkNext = 0;
+                chunkCount = chunkBase < a.totalWork
+                                 ? static_cast<uint32_t>(a.totalWork - chunkBase < kChunk ? a.totalWork - chunkBase : kChunk)
+                                 : 0u;
+                exhausted = chunkCount == 0;
+                if (chunkCount > 0)
+                {
+                    sortChunk(a, chunkBase, chunkCount, sortArea, rng);
+                }
             }
-            else
+            const uint32_t rank = lanesBelow(needMask);
+            const uint32_t avail = chunkCount - chunkNext;
+            const uint32_t n = static_cast<uint32_t>(__builtin_popcountll(needMask));
+            const bool served = need && rank < avail;
+            const unsigned long long id = served ? chunkBase + sortedIds[chunkNext + rank] : a.totalWork;
+            chunkNext += n < avail ? n : avail;
+            if (need && !served && exhausted)
             {
-                id = chunkNext + rank;
-                chunkNext += n;
+                finished = true;
             }
-            if (need)
+            if (served)
             {
-                if (id < a.totalWork)
                 {
                     lightId = static_cast<int>(id / a.photonCount);
                     photonIndex = a.firstPhoton + id % a.photonCount;
@@ -433,10 +540,6 @@ __global__ __launch_bounds__(kTraceThreads) void traceKernel(const TraceArgs a)
                     casts = 0;
                     valid = 0;
                     alive = true;
-                }
-                else
-                {
-                    finished = true;
                 }
             }
         }
@@ -1078,7 +1181,7 @@ void launchTrace(const TraceArgs& args, int blocks, int threads, hipStream_t str
 {
     (void)threads;
     const dim3 grid(blocks), block(kTraceThreads);
-    const size_t lds = stackBytes(args.scene, kTraceThreads);
+    const size_t lds = stackBytes(args.scene, kTraceThreads) + (kTraceThreads / 64) * kSortBytesPerWave;
     const bool record = args.records.recordPhotons > 0;
     switch (args.sinkMode)
     {
@@ -1102,7 +1205,8 @@ int traceBlocksPerCu(const SceneView& scene)
     int blocks = 0;
     // the grid is sized by the variant with the largest register footprint
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, traceKernel<kSinkSplat, true>, kTraceThreads,
-                                                     stackBytes(scene, kTraceThreads)) != hipSuccess ||
+                                                     stackBytes(scene, kTraceThreads) +
+                                                         (kTraceThreads / 64) * kSortBytesPerWave) != hipSuccess ||
         blocks < 1)
     {
         blocks = 2;
