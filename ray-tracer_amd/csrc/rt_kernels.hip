@@ -24,11 +24,12 @@ namespace
 {
 
 constexpr int kTraceThreads = 256;
-constexpr unsigned long long kChunk = 2048;  // photon ids a wave claims per atomic
-// Emission-order sort of a chunk (see sortChunk): grid cells per axis and the LDS a wave
-// needs for it: sorted ids (u16) + keys (u16) + cell counters (u32).
+constexpr unsigned long long kChunk = 4096;  // photon ids a wave claims per atomic
+// Emission-order sort of a chunk (see sortChunk): a grid of kSortAxis x kSortAxis cells and
+// the LDS a wave needs for it: sorted ids (u16) + cell counters (u32).  Two blocks of four
+// waves must fit a CU's 160 KB of LDS next to their traversal stacks.
 constexpr int kSortAxis = 32, kSortCells = kSortAxis * kSortAxis;
-constexpr int kSortBytesPerWave = static_cast<int>(kChunk) * 2 + static_cast<int>(kChunk) * 2 + kSortCells * 4;
+constexpr int kSortBytesPerWave = static_cast<int>(kChunk) * 2 + kSortCells * 4;
 constexpr double kSelfHitThreshold = 1e-4;   // reference src/Worker.cpp:36
 
 RT_DEV unsigned lanesBelow(unsigned long long mask)
@@ -342,7 +343,7 @@ RT_DEV void splatToCamera(const TraceArgs& a, const Vec& incoming, const Color& 
 }
 
 // A wave's chunk of photon ids is traced in EMISSION ORDER rather than id order: the ids
-// are bucketed by the cell of a kSortAxis x kSortAxis grid over the two uniform draws
+// are bucketed by the cell of a grid over the two uniform draws
 // that steer the photon's initial direction (cells in Morton order), so that the 64
 // photons a wave holds at any time leave the light in nearly the same direction, walk
 // nearly the same nodes and finish their casts together.  A photon's path depends only
@@ -357,12 +358,29 @@ RT_DEV uint32_t spreadBits5(uint32_t v)  // 5 bits -> every other bit
     return v;
 }
 
+// cell of photon `id` in the sort grid, in Morton order
+RT_DEV uint32_t sortKey(const TraceArgs& a, unsigned long long id, Rng& rng)
+{
+    const int lightId = static_cast<int>(id / a.photonCount);
+    const unsigned long long photonIndex = a.firstPhoton + id % a.photonCount;
+    rng.begin(static_cast<uint32_t>(lightId), photonIndex, RT_STAGE_EMIT);
+    double u0 = rng.value(), u1 = rng.value();
+    if (a.scene.lights[lightId].type == RT_LIGHT_AREA)
+    {
+        // an area light draws its origin first; the direction comes from draws 3 and 4
+        u0 = rng.value();
+        u1 = rng.value();
+    }
+    const uint32_t cx = static_cast<uint32_t>(u0 * kSortAxis) & (kSortAxis - 1);
+    const uint32_t cy = static_cast<uint32_t>(u1 * kSortAxis) & (kSortAxis - 1);
+    return spreadBits5(cx) | (spreadBits5(cy) << 1);
+}
+
 RT_DEV void sortChunk(const TraceArgs& a, unsigned long long chunkBase, uint32_t count, unsigned char* area, Rng& rng)
 {
     const int lane = threadIdx.x & 63;
     unsigned short* sorted = reinterpret_cast<unsigned short*>(area);
-    unsigned short* keys = sorted + kChunk;
-    uint32_t* cells = reinterpret_cast<uint32_t*>(keys + kChunk);
+    uint32_t* cells = reinterpret_cast<uint32_t*>(sorted + kChunk);
     for (int c = lane; c < kSortCells; c += 64)
     {
         cells[c] = 0;
@@ -371,34 +389,17 @@ RT_DEV void sortChunk(const TraceArgs& a, unsigned long long chunkBase, uint32_t
     __builtin_amdgcn_wave_barrier();
     for (uint32_t j = lane; j < count; j += 64)
     {
-        const unsigned long long id = chunkBase + j;
-        const int lightId = static_cast<int>(id / a.photonCount);
-        const unsigned long long photonIndex = a.firstPhoton + id % a.photonCount;
-        rng.begin(static_cast<uint32_t>(lightId), photonIndex, RT_STAGE_EMIT);
-        double u0 = rng.value(), u1 = rng.value();
-        if (a.scene.lights[lightId].type == RT_LIGHT_AREA)
-        {
-            // an area light draws its origin first; the direction comes from draws 3 and 4
-            u0 = rng.value();
-            u1 = rng.value();
-        }
-        const uint32_t cx = static_cast<uint32_t>(u0 * kSortAxis) & (kSortAxis - 1);
-        const uint32_t cy = static_cast<uint32_t>(u1 * kSortAxis) & (kSortAxis - 1);
-        const uint32_t key = spreadBits5(cx) | (spreadBits5(cy) << 1);
-        keys[j] = static_cast<unsigned short>(key);
-        atomicAdd(&cells[key], 1u);
+        atomicAdd(&cells[sortKey(a, chunkBase + j, rng)], 1u);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    // exclusive prefix sum of the cell counts: 16 consecutive cells per lane, then across lanes
+    // exclusive prefix sum of the cell counts: consecutive cells per lane, then across lanes
     constexpr int kPerLane = kSortCells / 64;
-    uint32_t local[kPerLane];
     uint32_t sum = 0;
-#pragma unroll
+#pragma unroll 4
     for (int k = 0; k < kPerLane; ++k)
     {
-        local[k] = cells[lane * kPerLane + k];
-        sum += local[k];
+        sum += cells[lane * kPerLane + k];
     }
     uint32_t scan = sum;
 #pragma unroll
@@ -408,17 +409,19 @@ RT_DEV void sortChunk(const TraceArgs& a, unsigned long long chunkBase, uint32_t
         if (lane >= offset) scan += other;
     }
     uint32_t running = scan - sum;
-#pragma unroll
+#pragma unroll 4
     for (int k = 0; k < kPerLane; ++k)
     {
+        const uint32_t c = cells[lane * kPerLane + k];
         cells[lane * kPerLane + k] = running;
-        running += local[k];
+        running += c;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    // the keys are recomputed rather than kept: two draws cost less than the LDS they would take
     for (uint32_t j = lane; j < count; j += 64)
     {
-        const uint32_t at = atomicAdd(&cells[keys[j]], 1u);
+        const uint32_t at = atomicAdd(&cells[sortKey(a, chunkBase + j, rng)], 1u);
         sorted[at] = static_cast<unsigned short>(j);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
