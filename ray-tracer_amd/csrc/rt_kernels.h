@@ -77,6 +77,7 @@ struct TraceArgs
     RecordView records;
     DeviceCounters* counters;
     unsigned long long* workCounter;
+    const uint32_t* emissionOrder;  // optional: position in the pass -> photon id, sorted by emission cell
     uint64_t firstPhoton;
     uint64_t photonCount;  // per light
     uint64_t totalWork;    // lights * photonCount
@@ -84,6 +85,12 @@ struct TraceArgs
     int32_t sinkMode;
 };
 
+// Global emission-order sort of the photon ids of one pass (see emissionCellKernel): counts
+// per cell, then (after an exclusive scan of `cells`) the scatter into `order`.
+constexpr int kGlobalSortBits = 20;  // cells per light = 2^kGlobalSortBits
+void launchEmissionCount(const TraceArgs& args, uint32_t* cells, hipStream_t stream);
+void launchEmissionScatter(const TraceArgs& args, uint32_t* cells, uint32_t* order, hipStream_t stream);
+size_t scanCells(void* scratch, size_t scratchBytes, uint32_t* cells, uint64_t count, hipStream_t stream);
 void launchTrace(const TraceArgs& args, int blocks, int threads, hipStream_t stream);
 void launchCastRays(const SceneView& scene, int64_t n, const double* rays, double selfHit, double* outF64,
                     int32_t* outI32, hipStream_t stream);

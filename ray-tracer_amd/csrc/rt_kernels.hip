@@ -359,8 +359,14 @@ RT_DEV uint32_t spreadBits5(uint32_t v)  // 5 bits -> every other bit
 }
 
 // cell of photon `id` in the sort grid, in Morton order
-RT_DEV uint32_t sortKey(const TraceArgs& a, unsigned long long id, Rng& rng)
+RT_DEV unsigned long long photonAt(const TraceArgs& a, unsigned long long position)
 {
+    return a.emissionOrder ? static_cast<unsigned long long>(a.emissionOrder[position]) : position;
+}
+
+RT_DEV uint32_t sortKey(const TraceArgs& a, unsigned long long position, Rng& rng)
+{
+    const unsigned long long id = photonAt(a, position);
     const int lightId = static_cast<int>(id / a.photonCount);
     const unsigned long long photonIndex = a.firstPhoton + id % a.photonCount;
     rng.begin(static_cast<uint32_t>(lightId), photonIndex, RT_STAGE_EMIT);
@@ -497,7 +503,7 @@ __global__ __launch_bounds__(kTraceThreads) void traceKernel(const TraceArgs a)
             const uint32_t avail = chunkCount - chunkNext;
             const uint32_t n = static_cast<uint32_t>(__builtin_popcountll(needMask));
             const bool served = need && rank < avail;
-            const unsigned long long id = served ? chunkBase + sortedIds[chunkNext + rank] : a.totalWork;
+            const unsigned long long id = served ? photonAt(a, chunkBase + sortedIds[chunkNext + rank]) : a.totalWork;
             chunkNext += n < avail ? n : avail;
             if (need && !served && exhausted)
             {
@@ -1153,6 +1159,66 @@ __global__ __launch_bounds__(256) void gatherKernel(const GatherArgs a)
     }
 }
 
+// ---------------------------------------------------------------- global emission-order sort
+// Before a large pass the photon ids are bucketed by emission cell over the WHOLE pass (a
+// counting sort: count per cell, exclusive scan, scatter), so that the ids a wave claims
+// together belong to one small cell of directions; the wave's own sort (sortChunk) then
+// orders them within that cell.  Cell = light, then a 2^10 x 2^10 Morton grid over the two
+// draws that steer the direction.  Purely a schedule: paths depend on ids only.
+RT_DEV uint32_t spreadBits10(uint32_t v)
+{
+    v = (v | (v << 8)) & 0x00FF00FFu;
+    v = (v | (v << 4)) & 0x0F0F0F0Fu;
+    v = (v | (v << 2)) & 0x33333333u;
+    v = (v | (v << 1)) & 0x55555555u;
+    return v;
+}
+
+RT_DEV uint32_t emissionCell(const TraceArgs& a, unsigned long long id, Rng& rng)
+{
+    const int lightId = static_cast<int>(id / a.photonCount);
+    const unsigned long long photonIndex = a.firstPhoton + id % a.photonCount;
+    rng.begin(static_cast<uint32_t>(lightId), photonIndex, RT_STAGE_EMIT);
+    double u0 = rng.value(), u1 = rng.value();
+    if (a.scene.lights[lightId].type == RT_LIGHT_AREA)
+    {
+        u0 = rng.value();
+        u1 = rng.value();
+    }
+    const uint32_t cx = static_cast<uint32_t>(u0 * 1024.0) & 1023u;
+    const uint32_t cy = static_cast<uint32_t>(u1 * 1024.0) & 1023u;
+    return (static_cast<uint32_t>(lightId) << kGlobalSortBits) | spreadBits10(cx) | (spreadBits10(cy) << 1);
+}
+
+__global__ void emissionCountKernel(const TraceArgs a, uint32_t* cells)
+{
+    Rng rng;
+    rng.tape = nullptr;
+    rng.next = 0;
+    rng.seed = a.scene.seed;
+    const unsigned long long stride = static_cast<unsigned long long>(gridDim.x) * blockDim.x;
+    for (unsigned long long id = static_cast<unsigned long long>(blockIdx.x) * blockDim.x + threadIdx.x; id < a.totalWork;
+         id += stride)
+    {
+        atomicAdd(&cells[emissionCell(a, id, rng)], 1u);
+    }
+}
+
+__global__ void emissionScatterKernel(const TraceArgs a, uint32_t* cells, uint32_t* order)
+{
+    Rng rng;
+    rng.tape = nullptr;
+    rng.next = 0;
+    rng.seed = a.scene.seed;
+    const unsigned long long stride = static_cast<unsigned long long>(gridDim.x) * blockDim.x;
+    for (unsigned long long id = static_cast<unsigned long long>(blockIdx.x) * blockDim.x + threadIdx.x; id < a.totalWork;
+         id += stride)
+    {
+        const uint32_t at = atomicAdd(&cells[emissionCell(a, id, rng)], 1u);
+        order[at] = static_cast<uint32_t>(id);
+    }
+}
+
 int gridFor(int64_t n) { return static_cast<int>((n + 255) / 256); }
 
 // dynamic LDS of a kernel that casts rays: one traversal stack per lane
@@ -1179,6 +1245,23 @@ void printDiagnostics()
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_rtDiag), zero, sizeof(zero));
 }
 #endif
+
+void launchEmissionCount(const TraceArgs& args, uint32_t* cells, hipStream_t stream)
+{
+    hipLaunchKernelGGL(emissionCountKernel, dim3(256 * 16), dim3(256), 0, stream, args, cells);
+}
+
+void launchEmissionScatter(const TraceArgs& args, uint32_t* cells, uint32_t* order, hipStream_t stream)
+{
+    hipLaunchKernelGGL(emissionScatterKernel, dim3(256 * 16), dim3(256), 0, stream, args, cells, order);
+}
+
+size_t scanCells(void* scratch, size_t scratchBytes, uint32_t* cells, uint64_t count, hipStream_t stream)
+{
+    size_t bytes = scratchBytes;
+    (void)hipcub::DeviceScan::ExclusiveSum(scratch, bytes, cells, cells, static_cast<int>(count), stream);
+    return bytes;
+}
 
 void launchTrace(const TraceArgs& args, int blocks, int threads, hipStream_t stream)
 {
