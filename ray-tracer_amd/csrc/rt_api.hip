@@ -157,9 +157,8 @@ struct rt_tracer
     // shared device scalars: [0] work counter, [1] store cursor
     DeviceArray<unsigned long long> scalars;
     DeviceArray<rtd::DeviceCounters> counters;
-    // global emission-order sort of a pass
-    DeviceArray<uint32_t> sortCells, sortOrder;
-    DeviceArray<unsigned char> sortScratch;
+    // emission-order list of a pass's photon ids
+    DeviceArray<uint32_t> sortOrder;
 
     // records of the last trace
     uint64_t recordPhotons = 0;
@@ -923,20 +922,12 @@ int32_t rt_trace(rt_tracer* tracer, const rt_trace_params* params)
         {
             return;
         }
-        // large passes are traced in emission order (a schedule only; see emissionCellKernel)
+        // large passes are traced in emission order (a schedule only; see emissionTileKernel)
         args.emissionOrder = nullptr;
-        const uint64_t sortCells = static_cast<uint64_t>(tracer->lightCount) << rtd::kGlobalSortBits;
-        if (args.totalWork >= (1ull << 20) && args.totalWork < (1ull << 32) && sortCells <= (1ull << 24))
+        if (args.totalWork >= (1ull << 20) && args.totalWork < (1ull << 32))
         {
-            if (tracer->sortCells.count < sortCells) tracer->sortCells.allocate(sortCells);
             if (tracer->sortOrder.count < args.totalWork) tracer->sortOrder.allocate(args.totalWork);
-            check(hipMemsetAsync(tracer->sortCells.ptr, 0, sortCells * sizeof(uint32_t), tracer->stream),
-                  "hipMemsetAsync sort cells");
-            rtd::launchEmissionCount(args, tracer->sortCells.ptr, tracer->stream);
-            const size_t bytes = rtd::scanCells(nullptr, 0, tracer->sortCells.ptr, sortCells, tracer->stream);
-            if (tracer->sortScratch.count < bytes) tracer->sortScratch.allocate(bytes);
-            rtd::scanCells(tracer->sortScratch.ptr, bytes, tracer->sortCells.ptr, sortCells, tracer->stream);
-            rtd::launchEmissionScatter(args, tracer->sortCells.ptr, tracer->sortOrder.ptr, tracer->stream);
+            rtd::launchEmissionTiles(args, tracer->sortOrder.ptr, tracer->stream);
             check(hipGetLastError(), "emission sort launch");
             args.emissionOrder = tracer->sortOrder.ptr;
         }

@@ -85,12 +85,10 @@ struct TraceArgs
     int32_t sinkMode;
 };
 
-// Global emission-order sort of the photon ids of one pass (see emissionCellKernel): counts
-// per cell, then (after an exclusive scan of `cells`) the scatter into `order`.
-constexpr int kGlobalSortBits = 20;  // cells per light = 2^kGlobalSortBits
-void launchEmissionCount(const TraceArgs& args, uint32_t* cells, hipStream_t stream);
-void launchEmissionScatter(const TraceArgs& args, uint32_t* cells, uint32_t* order, hipStream_t stream);
-size_t scanCells(void* scratch, size_t scratchBytes, uint32_t* cells, uint64_t count, hipStream_t stream);
+// Tile-wise emission-order sort of the photon ids of one pass (see emissionTileKernel).
+constexpr int kTileBits = 18;       // ids per tile = 2^kTileBits
+constexpr int kTileAxisBits = 7;    // a tile is bucketed into a 128 x 128 grid
+void launchEmissionTiles(const TraceArgs& args, uint32_t* order, hipStream_t stream);
 void launchTrace(const TraceArgs& args, int blocks, int threads, hipStream_t stream);
 void launchCastRays(const SceneView& scene, int64_t n, const double* rays, double selfHit, double* outF64,
                     int32_t* outI32, hipStream_t stream);

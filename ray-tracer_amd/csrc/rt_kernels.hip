@@ -377,8 +377,12 @@ RT_DEV uint32_t sortKey(const TraceArgs& a, unsigned long long position, Rng& rn
         u0 = rng.value();
         u1 = rng.value();
     }
-    const uint32_t cx = static_cast<uint32_t>(u0 * kSortAxis) & (kSortAxis - 1);
-    const uint32_t cy = static_cast<uint32_t>(u1 * kSortAxis) & (kSortAxis - 1);
+    // after the tile sort a chunk is a run of about 16 x 16 neighbouring cells of the tile's
+    // 128 x 128 grid: order it by a grid twice as fine, whose cell numbers (taken modulo the
+    // 32 x 32 buckets) are distinct across such a run
+    const double scale = a.emissionOrder ? static_cast<double>(2 << kTileAxisBits) : 1.0 * kSortAxis;
+    const uint32_t cx = static_cast<uint32_t>(u0 * scale) & (kSortAxis - 1);
+    const uint32_t cy = static_cast<uint32_t>(u1 * scale) & (kSortAxis - 1);
     return spreadBits5(cx) | (spreadBits5(cy) << 1);
 }
 
@@ -1159,18 +1163,22 @@ __global__ __launch_bounds__(256) void gatherKernel(const GatherArgs a)
     }
 }
 
-// ---------------------------------------------------------------- global emission-order sort
-// Before a large pass the photon ids are bucketed by emission cell over the WHOLE pass (a
-// counting sort: count per cell, exclusive scan, scatter), so that the ids a wave claims
-// together belong to one small cell of directions; the wave's own sort (sortChunk) then
-// orders them within that cell.  Cell = light, then a 2^10 x 2^10 Morton grid over the two
-// draws that steer the direction.  Purely a schedule: paths depend on ids only.
-RT_DEV uint32_t spreadBits10(uint32_t v)
+// ---------------------------------------------------------------- tile-wise emission-order sort
+// Before a large pass the photon ids are bucketed by emission cell, tile by tile: one block
+// takes 2^kTileBits consecutive ids, counts them per cell of a 128 x 128 Morton grid over the
+// two draws that steer the direction (histogram in LDS), scans the counts and scatters the ids
+// into the tile's own stretch of `order`.  A wave of the trace kernel then claims consecutive
+// positions of `order`, i.e. ids of a few neighbouring cells, and its own sort (sortChunk)
+// orders them within those cells.  No global atomics, and every write lands inside the tile's
+// 1 MB stretch.  Purely a schedule: paths depend on ids only.
+constexpr int kTileThreads = 1024;
+constexpr int kTileCells = 1 << (2 * kTileAxisBits);
+
+RT_DEV uint32_t spreadBits8(uint32_t v)
 {
-    v = (v | (v << 8)) & 0x00FF00FFu;
-    v = (v | (v << 4)) & 0x0F0F0F0Fu;
-    v = (v | (v << 2)) & 0x33333333u;
-    v = (v | (v << 1)) & 0x55555555u;
+    v = (v | (v << 4)) & 0x0F0Fu;
+    v = (v | (v << 2)) & 0x3333u;
+    v = (v | (v << 1)) & 0x5555u;
     return v;
 }
 
@@ -1185,37 +1193,71 @@ RT_DEV uint32_t emissionCell(const TraceArgs& a, unsigned long long id, Rng& rng
         u0 = rng.value();
         u1 = rng.value();
     }
-    const uint32_t cx = static_cast<uint32_t>(u0 * 1024.0) & 1023u;
-    const uint32_t cy = static_cast<uint32_t>(u1 * 1024.0) & 1023u;
-    return (static_cast<uint32_t>(lightId) << kGlobalSortBits) | spreadBits10(cx) | (spreadBits10(cy) << 1);
+    const uint32_t axis = 1u << kTileAxisBits;
+    const uint32_t cx = static_cast<uint32_t>(u0 * axis) & (axis - 1);
+    const uint32_t cy = static_cast<uint32_t>(u1 * axis) & (axis - 1);
+    return spreadBits8(cx) | (spreadBits8(cy) << 1);
 }
 
-__global__ void emissionCountKernel(const TraceArgs a, uint32_t* cells)
+__global__ __launch_bounds__(kTileThreads) void emissionTileKernel(const TraceArgs a, uint32_t* order)
 {
+    __shared__ uint32_t cells[kTileCells];
+    __shared__ uint32_t waveTotals[kTileThreads / 64];
     Rng rng;
     rng.tape = nullptr;
     rng.next = 0;
     rng.seed = a.scene.seed;
-    const unsigned long long stride = static_cast<unsigned long long>(gridDim.x) * blockDim.x;
-    for (unsigned long long id = static_cast<unsigned long long>(blockIdx.x) * blockDim.x + threadIdx.x; id < a.totalWork;
-         id += stride)
+    const unsigned long long tileBase = static_cast<unsigned long long>(blockIdx.x) << kTileBits;
+    const unsigned long long tileEnd =
+        tileBase + (1ull << kTileBits) < a.totalWork ? tileBase + (1ull << kTileBits) : a.totalWork;
+    for (int c = threadIdx.x; c < kTileCells; c += kTileThreads)
+    {
+        cells[c] = 0;
+    }
+    __syncthreads();
+    for (unsigned long long id = tileBase + threadIdx.x; id < tileEnd; id += kTileThreads)
     {
         atomicAdd(&cells[emissionCell(a, id, rng)], 1u);
     }
-}
-
-__global__ void emissionScatterKernel(const TraceArgs a, uint32_t* cells, uint32_t* order)
-{
-    Rng rng;
-    rng.tape = nullptr;
-    rng.next = 0;
-    rng.seed = a.scene.seed;
-    const unsigned long long stride = static_cast<unsigned long long>(gridDim.x) * blockDim.x;
-    for (unsigned long long id = static_cast<unsigned long long>(blockIdx.x) * blockDim.x + threadIdx.x; id < a.totalWork;
-         id += stride)
+    __syncthreads();
+    // exclusive scan of the counts: consecutive cells per thread, then across the block
+    constexpr int kPerThread = kTileCells / kTileThreads;
+    uint32_t sum = 0;
+#pragma unroll
+    for (int k = 0; k < kPerThread; ++k)
+    {
+        sum += cells[threadIdx.x * kPerThread + k];
+    }
+    uint32_t scan = sum;
+#pragma unroll
+    for (int offset = 1; offset < 64; offset <<= 1)
+    {
+        const uint32_t other = __shfl_up(scan, offset, 64);
+        if (static_cast<int>(threadIdx.x & 63) >= offset) scan += other;
+    }
+    if ((threadIdx.x & 63) == 63)
+    {
+        waveTotals[threadIdx.x >> 6] = scan;
+    }
+    __syncthreads();
+    uint32_t before = 0;
+    for (int w = 0; w < static_cast<int>(threadIdx.x >> 6); ++w)
+    {
+        before += waveTotals[w];
+    }
+    uint32_t running = before + scan - sum;
+#pragma unroll
+    for (int k = 0; k < kPerThread; ++k)
+    {
+        const uint32_t c = cells[threadIdx.x * kPerThread + k];
+        cells[threadIdx.x * kPerThread + k] = running;
+        running += c;
+    }
+    __syncthreads();
+    for (unsigned long long id = tileBase + threadIdx.x; id < tileEnd; id += kTileThreads)
     {
         const uint32_t at = atomicAdd(&cells[emissionCell(a, id, rng)], 1u);
-        order[at] = static_cast<uint32_t>(id);
+        order[tileBase + at] = static_cast<uint32_t>(id);
     }
 }
 
@@ -1246,21 +1288,10 @@ void printDiagnostics()
 }
 #endif
 
-void launchEmissionCount(const TraceArgs& args, uint32_t* cells, hipStream_t stream)
+void launchEmissionTiles(const TraceArgs& args, uint32_t* order, hipStream_t stream)
 {
-    hipLaunchKernelGGL(emissionCountKernel, dim3(256 * 16), dim3(256), 0, stream, args, cells);
-}
-
-void launchEmissionScatter(const TraceArgs& args, uint32_t* cells, uint32_t* order, hipStream_t stream)
-{
-    hipLaunchKernelGGL(emissionScatterKernel, dim3(256 * 16), dim3(256), 0, stream, args, cells, order);
-}
-
-size_t scanCells(void* scratch, size_t scratchBytes, uint32_t* cells, uint64_t count, hipStream_t stream)
-{
-    size_t bytes = scratchBytes;
-    (void)hipcub::DeviceScan::ExclusiveSum(scratch, bytes, cells, cells, static_cast<int>(count), stream);
-    return bytes;
+    const unsigned long long tiles = (args.totalWork + (1ull << kTileBits) - 1) >> kTileBits;
+    hipLaunchKernelGGL(emissionTileKernel, dim3(static_cast<unsigned>(tiles)), dim3(kTileThreads), 0, stream, args, order);
 }
 
 void launchTrace(const TraceArgs& args, int blocks, int threads, hipStream_t stream)
