@@ -86,7 +86,7 @@ struct TraceArgs
 };
 
 // Tile-wise emission-order sort of the photon ids of one pass (see emissionTileKernel).
-constexpr int kTileBits = 18;       // ids per tile = 2^kTileBits
+constexpr int kTileBits = 20;       // ids per tile = 2^kTileBits
 constexpr int kTileAxisBits = 7;    // a tile is bucketed into a 128 x 128 grid
 void launchEmissionTiles(const TraceArgs& args, uint32_t* order, hipStream_t stream);
 void launchTrace(const TraceArgs& args, int blocks, int threads, hipStream_t stream);

@@ -377,10 +377,14 @@ RT_DEV uint32_t sortKey(const TraceArgs& a, unsigned long long position, Rng& rn
         u0 = rng.value();
         u1 = rng.value();
     }
-    // after the tile sort a chunk is a run of about 16 x 16 neighbouring cells of the tile's
-    // 128 x 128 grid: order it by a grid twice as fine, whose cell numbers (taken modulo the
-    // 32 x 32 buckets) are distinct across such a run
-    const double scale = a.emissionOrder ? static_cast<double>(2 << kTileAxisBits) : 1.0 * kSortAxis;
+    // after the tile sort a chunk is a run of kChunk / (tile ids per cell) neighbouring cells of
+    // the tile's grid, about a square of `side` cells: order it by a grid kSortAxis / side times
+    // as fine, whose cell numbers (taken modulo the kSortAxis x kSortAxis buckets) are distinct
+    // across such a run
+    constexpr int kCellsPerChunk = static_cast<int>(kChunk >> (kTileBits - 2 * kTileAxisBits));
+    constexpr int kSide = kCellsPerChunk >= 256 ? 16 : (kCellsPerChunk >= 64 ? 8 : (kCellsPerChunk >= 16 ? 4 : 2));
+    const double scale =
+        a.emissionOrder ? static_cast<double>((kSortAxis / kSide) << kTileAxisBits) : 1.0 * kSortAxis;
     const uint32_t cx = static_cast<uint32_t>(u0 * scale) & (kSortAxis - 1);
     const uint32_t cy = static_cast<uint32_t>(u1 * scale) & (kSortAxis - 1);
     return spreadBits5(cx) | (spreadBits5(cy) << 1);
