@@ -12,7 +12,11 @@ all-reduce.  Inputs (scene, tree, probe grid) are resident in HBM before the tim
 region.  The metric counts ray casts that produced a valid hit.
 
 Rank 0 prints ONE JSON line; see DESIGN.md "Measurement" for how `roofline` and
-`cpu_baseline` are defined.
+`cpu_baseline` are defined.  `roofline` is that of the dominant kernel, traceKernel: its
+duration comes from HIP events the library records on the tracer's stream around that
+kernel (rt_read_timings); `roofline.traffic` is the HBM byte count of the same launch
+measured with rocprofv3 PMC passes and committed in profiles/traffic.json (null when the
+run's configuration has no committed measurement).
 """
 import argparse
 import importlib
@@ -58,7 +62,8 @@ def main():
                     help="weak: every GPU traces the scene's full photon budget (global budget = N x scene); "
                          "strong: the scene's budget is split across the GPUs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-photons", type=int, default=4_000_000)
+    ap.add_argument("--cpu-photons", type=int, default=40_000_000,
+                    help="photons per light of the CPU baseline sample (about 20 s of CPU work)")
     args = ap.parse_args()
 
     import numpy as np
@@ -108,17 +113,11 @@ def main():
     first, count = parallel.shard_range(photons, rank, world)
     sink_mode = {"none": rt.tracer.SINK_NONE, "probe": rt.tracer.SINK_PROBE, "splat": rt.tracer.SINK_SPLAT}[sink]
 
-    start_evt = torch.cuda.Event(enable_timing=True)
-    stop_evt = torch.cuda.Event(enable_timing=True)
-    kernel_ms = []
+    kernel_ms, sort_ms = [], []
 
     def step(timed):
         tracer.reset()
-        if timed:
-            start_evt.record(stream)
         tracer.trace(sink_mode=sink_mode, first_photon=first, photon_count=count)
-        if timed:
-            stop_evt.record(stream)
         if world > 1:
             for t in buffers:
                 dist.all_reduce(t)
@@ -127,7 +126,9 @@ def main():
         if world > 1:
             dist.all_reduce(totals)
         if timed:
-            kernel_ms.append(start_evt.elapsed_time(stop_evt))
+            s_ms, t_ms = tracer.timings()
+            sort_ms.append(s_ms)
+            kernel_ms.append(t_ms)
         return dict(zip(counter_names, [int(v) for v in totals.tolist()]))
 
     def fence():
@@ -167,6 +168,15 @@ def main():
         algorithmic = casts * per_cast + sink_bytes
         avg_kernel_s = 1e-3 * sum(kernel_ms) / max(1, len(kernel_ms))
         achieved = algorithmic / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
+        traffic = None
+        try:
+            with open(os.path.join(REPO, "profiles", "traffic.json")) as f:
+                for entry in json.load(f)["launches"]:
+                    if (entry["workload"] == os.path.basename(args.scene).replace(".json", "")
+                            and entry["sink"] == sink and entry["photons_per_launch"] == count * lights):
+                        traffic = entry["hbm_bytes"]
+        except (OSError, KeyError, ValueError):
+            traffic = None
         out = {
             "metric": "photon-bounces/sec (whole node), MirrorBombardment-200M",
             "value": value,
@@ -199,11 +209,28 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic,
+                "kernel": "traceKernel",
                 "kernel_ms": 1e3 * avg_kernel_s,
+                "sort_kernel_ms": sum(sort_ms) / max(1, len(sort_ms)),
+                "algorithmic_bytes": algorithmic,
                 "algorithmic_bytes_per_cast": per_cast,
             },
         }
+        # secondary bound: FP64 vector issue.  Flops per cast as priced for this path: per mesh volume
+        # 150 (ray transform) + 2 * depth * 30 (slab tests) + 2 * 90 (triangle tests); peak = 256 CUs x
+        # 4 SIMDs x 16 lanes x 2.4 GHz = 39.3 TFLOP/s for individually rounded operations (no FMA contraction)
+        flops_per_cast = 0.0
+        for v in range(desc.volume_count):
+            vol = desc.volumes[v]
+            if vol.type == 0:
+                tris = max(1, desc.meshes[vol.mesh].triangle_count)
+                flops_per_cast += 150 + 2 * max(1, math.ceil(math.log2(tris))) * 30 + 2 * 90
+            else:
+                flops_per_cast += 150 + 40
+        valu = casts * flops_per_cast / avg_kernel_s / 1e12 if avg_kernel_s > 0 else 0.0
+        out["roofline_valu"] = {"bound": "fp64-valu", "achieved": valu, "peak": 39.3, "unit": "TFLOP/s",
+                                "frac": valu / 39.3, "flops_per_cast": flops_per_cast}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = frame.cpu_baseline(rt, args.scene, sink, setup, args.cpu_photons)
         print(json.dumps(out), flush=True)

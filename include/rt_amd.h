@@ -126,6 +126,13 @@ int32_t rt_reset(rt_tracer* tracer);
 int32_t rt_trace(rt_tracer* tracer, const rt_trace_params* params);
 int32_t rt_synchronize(rt_tracer* tracer);
 
+/* Device time of the last rt_trace, from HIP events recorded on the tracer's stream around
+ * its two stages: the emission-order sort of the photon ids (0 when the pass was too small
+ * to be sorted) and the trace kernel.  The reference reports one wall time for the whole pass
+ * (RenderResult::photonPassSeconds, include/Renderer.h:51-103); the split is what a
+ * per-kernel roofline needs.  Waits for the pass to finish. */
+int32_t rt_read_timings(rt_tracer* tracer, float* sort_ms, float* trace_ms);
+
 int32_t rt_read_counters(rt_tracer* tracer, rt_counters* out);
 /* Buffer::fetchColor over the whole image: rgb [h][w][3] (reference src/Buffer.cpp:39-53). */
 int32_t rt_read_camera_buffer(rt_tracer* tracer, int32_t camera, float* rgb);

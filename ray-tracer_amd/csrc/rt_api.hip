@@ -159,6 +159,9 @@ struct rt_tracer
     DeviceArray<rtd::DeviceCounters> counters;
     // emission-order list of a pass's photon ids
     DeviceArray<uint32_t> sortOrder;
+    // events around the stages of the last rt_trace: before the sort, after it, after the trace kernel
+    hipEvent_t stageEvents[3] = {nullptr, nullptr, nullptr};
+    bool timed = false;
 
     // records of the last trace
     uint64_t recordPhotons = 0;
@@ -651,6 +654,10 @@ void rt_destroy(rt_tracer* tracer)
     {
         (void)hipSetDevice(tracer->device);
         (void)hipDeviceSynchronize();
+        for (hipEvent_t e : tracer->stageEvents)
+        {
+            if (e != nullptr) (void)hipEventDestroy(e);
+        }
 #ifdef RT_DIAG
         rtd::printDiagnostics();
 #endif
@@ -922,6 +929,11 @@ int32_t rt_trace(rt_tracer* tracer, const rt_trace_params* params)
         {
             return;
         }
+        for (hipEvent_t& e : tracer->stageEvents)
+        {
+            if (e == nullptr) check(hipEventCreate(&e), "hipEventCreate");
+        }
+        check(hipEventRecord(tracer->stageEvents[0], tracer->stream), "hipEventRecord");
         // large passes are traced in emission order (a schedule only; see emissionTileKernel)
         args.emissionOrder = nullptr;
         if (args.totalWork >= (1ull << 20) && args.totalWork < (1ull << 32))
@@ -931,10 +943,28 @@ int32_t rt_trace(rt_tracer* tracer, const rt_trace_params* params)
             check(hipGetLastError(), "emission sort launch");
             args.emissionOrder = tracer->sortOrder.ptr;
         }
+        check(hipEventRecord(tracer->stageEvents[1], tracer->stream), "hipEventRecord");
         const uint64_t wavesNeeded = (args.totalWork + 63) / 64;
         const int blocks = static_cast<int>(std::min<uint64_t>(static_cast<uint64_t>(tracer->blocks), (wavesNeeded + 3) / 4));
         rtd::launchTrace(args, std::max(1, blocks), 256, tracer->stream);
         check(hipGetLastError(), "trace launch");
+        check(hipEventRecord(tracer->stageEvents[2], tracer->stream), "hipEventRecord");
+        tracer->timed = true;
+    });
+}
+
+int32_t rt_read_timings(rt_tracer* tracer, float* sort_ms, float* trace_ms)
+{
+    return guarded([&]() {
+        require(tracer != nullptr && sort_ms != nullptr && trace_ms != nullptr, "null argument");
+        if (!tracer->timed)
+        {
+            throw ApiError(RT_ERR_STATE, "rt_read_timings needs a completed rt_trace");
+        }
+        activate(tracer);
+        check(hipEventSynchronize(tracer->stageEvents[2]), "hipEventSynchronize");
+        check(hipEventElapsedTime(sort_ms, tracer->stageEvents[0], tracer->stageEvents[1]), "hipEventElapsedTime");
+        check(hipEventElapsedTime(trace_ms, tracer->stageEvents[1], tracer->stageEvents[2]), "hipEventElapsedTime");
     });
 }
 

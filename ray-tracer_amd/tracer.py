@@ -44,6 +44,7 @@ _SIGNATURES = {
     "rt_reset": (C.c_int32, [C.c_void_p]),
     "rt_trace": (C.c_int32, [C.c_void_p, C.POINTER(RtTraceParams)]),
     "rt_synchronize": (C.c_int32, [C.c_void_p]),
+    "rt_read_timings": (C.c_int32, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "rt_read_counters": (C.c_int32, [C.c_void_p, C.POINTER(RtCounters)]),
     "rt_read_camera_buffer": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p]),
     "rt_read_store": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
@@ -167,6 +168,12 @@ class Tracer:
 
     def synchronize(self):
         _check(tracer_lib().rt_synchronize(self._handle))
+
+    def timings(self):
+        """(sort_ms, trace_ms) of the last pass, from HIP events on the tracer's stream."""
+        sort_ms, trace_ms = C.c_float(), C.c_float()
+        _check(tracer_lib().rt_read_timings(self._handle, C.byref(sort_ms), C.byref(trace_ms)))
+        return float(sort_ms.value), float(trace_ms.value)
 
     # -- read-back ----------------------------------------------------------
     def counters(self):
