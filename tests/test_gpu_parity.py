@@ -179,6 +179,37 @@ def test_probe_sink_store_equals_oracle(rt, scene_opener, name):
     assert c["store_size"] == small and c["store_dropped"] == ref["kept"] - small and c["store_attempted"] == ref["kept"]
 
 
+@pytest.mark.parametrize("name,photons", [("bombardment", 1_300_000), ("mixed", 250_000)])
+def test_sorted_pass_equals_oracle(rt, scene_opener, name, photons):
+    """Passes of 2^20 photons and more are traced in emission order (tile sort + chunk sort).
+    The schedule must not change any result: same counters, same store multiset, same paths
+    for the recorded photons (record slots follow photon ids, not the schedule)."""
+    entry = dict(SCENES[name], photons_per_light=photons)
+    scene, tracer, orc = _open(rt, scene_opener, entry)
+    assert photons * scene.desc.light_count >= 1 << 20
+    setup = O.frame_setup(orc, O.RNG_COUNTER, O.MATH_PORTABLE)
+    keep = setup["keep_radius"]
+    capacity = 1 << 22
+    ref = orc.trace(rng_mode=O.RNG_COUNTER, math_mode=O.MATH_PORTABLE, threads=8, sink_mode=O.SINK_PROBE,
+                    probes=setup["probes"], probe_cell_size=keep, keep_radius=keep, store_capacity=capacity,
+                    record_photons=5000)
+    tracer.set_probes(setup["probes"], keep, keep, capacity)
+    tracer.reset()
+    tracer.trace(sink_mode=1, record_photons=5000)
+    c = tracer.counters()
+    for k in ("photons", "casts", "bounces", "deposits", "kept", "culled", "store_size"):
+        assert c[k] == ref[k], k
+    assert ref["kept"] > 1000
+    assert_bits_equal(_sorted_records(tracer.store()), _sorted_records(ref["store"]), "store records")
+    got = tracer.records()
+    assert_bits_equal(got["emitted"], ref["emitted"], "emitted")
+    assert np.array_equal(got["casts_valid"], ref["casts_valid"])
+    assert_bits_equal(got["bounce_f64"], ref["bounce_f64"], "hits")
+    assert np.array_equal(got["bounce_i32"], ref["bounce_i32"]), "ids"
+    sort_ms, trace_ms = tracer.timings()
+    assert sort_ms > 0.0 and trace_ms > 0.0
+
+
 PROBE_SCENES = {
     "mixed": {"scene": "tests/scenes/mixed.json"},
     "bombardment": {"scene": "scenes/MirrorBombardment-200M.json", "image": 160, "seed": 11},
