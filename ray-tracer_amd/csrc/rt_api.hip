@@ -944,6 +944,13 @@ int32_t rt_trace(rt_tracer* tracer, const rt_trace_params* params)
             args.emissionOrder = tracer->sortOrder.ptr;
         }
         check(hipEventRecord(tracer->stageEvents[1], tracer->stream), "hipEventRecord");
+        // every resident wave should see several chunks: small passes use small chunks
+        {
+            const uint64_t waves = static_cast<uint64_t>(tracer->blocks) * 4;
+            uint64_t chunk = args.totalWork / (waves * 4);
+            chunk = std::min<uint64_t>(4096, std::max<uint64_t>(64, chunk)) & ~63ull;
+            args.chunk = static_cast<uint32_t>(chunk);
+        }
         const uint64_t wavesNeeded = (args.totalWork + 63) / 64;
         const int blocks = static_cast<int>(std::min<uint64_t>(static_cast<uint64_t>(tracer->blocks), (wavesNeeded + 3) / 4));
         rtd::launchTrace(args, std::max(1, blocks), 256, tracer->stream);

@@ -77,6 +77,7 @@ struct TraceArgs
     RecordView records;
     DeviceCounters* counters;
     unsigned long long* workCounter;
+    uint32_t chunk;                 // photon ids a wave claims at a time (<= 4096, multiple of 64)
     const uint32_t* emissionOrder;  // optional: position in the pass -> photon id, sorted by emission cell
     uint64_t firstPhoton;
     uint64_t photonCount;  // per light

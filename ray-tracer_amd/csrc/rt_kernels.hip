@@ -24,7 +24,7 @@ namespace
 {
 
 constexpr int kTraceThreads = 256;
-constexpr unsigned long long kChunk = 4096;  // photon ids a wave claims per atomic
+constexpr unsigned long long kChunk = 4096;  // most photon ids a wave claims per atomic (TraceArgs::chunk)
 // Emission-order sort of a chunk (see sortChunk): a grid of kSortAxis x kSortAxis cells and
 // the LDS a wave needs for it: sorted ids (u16) + cell counters (u32).  Two blocks of four
 // waves must fit a CU's 160 KB of LDS next to their traversal stacks.
@@ -381,6 +381,7 @@ RT_DEV uint32_t sortKey(const TraceArgs& a, unsigned long long position, Rng& rn
     // the tile's grid, about a square of `side` cells: order it by a grid kSortAxis / side times
     // as fine, whose cell numbers (taken modulo the kSortAxis x kSortAxis buckets) are distinct
     // across such a run
+    // (sized for a full chunk; a smaller chunk of a small pass is merely sorted finer than needed)
     constexpr int kCellsPerChunk = static_cast<int>(kChunk >> (kTileBits - 2 * kTileAxisBits));
     constexpr int kSide = kCellsPerChunk >= 256 ? 16 : (kCellsPerChunk >= 64 ? 8 : (kCellsPerChunk >= 16 ? 4 : 2));
     const double scale =
@@ -494,12 +495,12 @@ __global__ __launch_bounds__(kTraceThreads) void traceKernel(const TraceArgs a)
                 unsigned long long fresh = 0;
                 if (lane == 0)
                 {
-                    fresh = atomicAdd(a.workCounter, kChunk);
+                    fresh = atomicAdd(a.workCounter, static_cast<unsigned long long>(a.chunk));
                 }
                 chunkBase = __shfl(fresh, 0, 64);
                 chunkNext = 0;
                 chunkCount = chunkBase < a.totalWork
-                                 ? static_cast<uint32_t>(a.totalWork - chunkBase < kChunk ? a.totalWork - chunkBase : kChunk)
+                                 ? static_cast<uint32_t>(a.totalWork - chunkBase < a.chunk ? a.totalWork - chunkBase : a.chunk)
                                  : 0u;
                 exhausted = chunkCount == 0;
                 if (chunkCount > 0)
