@@ -546,6 +546,108 @@ rt_tracer::GatherCache& ensureGatherPoints(rt_tracer* tracer, int32_t camera)
     return cache;
 }
 
+// Device-side build of the probe grid.  Returns false (nothing changed) when the general host
+// build must be used: a keep radius that spans more than one cell, or cell coordinates beyond
+// the packable +-2^20 range.
+bool buildProbesOnDevice(rt_tracer* tracer, const double* probes, uint64_t n, double invCellSize, double keepRadius)
+{
+    const int64_t reach = static_cast<int64_t>(std::ceil(keepRadius * invCellSize));
+    if (n == 0 || reach != 1 || n >= (1ull << 31) / 27)
+    {
+        return false;
+    }
+    hipStream_t stream = tracer->stream;
+    DeviceArray<double> points;
+    DeviceArray<unsigned long long> keysIn, keysOut, scalars;
+    DeviceArray<uint32_t> orderIn, orderOut, flag;
+    DeviceArray<unsigned char> scratch;
+    points.allocate(3 * n);
+    keysIn.allocate(n);
+    keysOut.allocate(n);
+    orderIn.allocate(n);
+    orderOut.allocate(n);
+    flag.allocate(1);
+    scalars.allocate(2);
+    flag.zero(stream);
+    scalars.zero(stream);
+    check(hipMemcpyAsync(points.ptr, probes, 3 * n * sizeof(double), hipMemcpyHostToDevice, stream), "hipMemcpyAsync probes");
+    rtd::ProbeBuild build{points.ptr, n, invCellSize, keysIn.ptr, orderIn.ptr};
+    rtd::launchProbeKeys(build, flag.ptr, stream);
+    uint32_t unpackable = 0;
+    check(hipMemcpyAsync(&unpackable, flag.ptr, sizeof(unpackable), hipMemcpyDeviceToHost, stream), "hipMemcpyAsync flag");
+    check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+    if (unpackable != 0)
+    {
+        return false;
+    }
+    size_t bytes = rtd::sortKeyPairs(nullptr, 0, keysIn.ptr, keysOut.ptr, orderIn.ptr, orderOut.ptr, n, stream);
+    scratch.allocate(std::max<size_t>(bytes, 1));
+    rtd::sortKeyPairs(scratch.ptr, bytes, keysIn.ptr, keysOut.ptr, orderIn.ptr, orderOut.ptr, n, stream);
+    rtd::launchCountRuns(keysOut.ptr, n, scalars.ptr, stream);
+    unsigned long long cellCount = 0;
+    check(hipMemcpyAsync(&cellCount, scalars.ptr, sizeof(cellCount), hipMemcpyDeviceToHost, stream), "hipMemcpyAsync runs");
+    check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+
+    uint64_t slots = 16;
+    while (slots < 2 * cellCount + 1)
+    {
+        slots <<= 1;
+    }
+    tracer->slotKey.allocate(3 * slots);
+    tracer->slotStart.allocate(slots);
+    tracer->slotCount.allocate(slots);
+    tracer->probePoints.allocate(3 * n);
+    tracer->slotCount.zero(stream);
+    rtd::launchProbeTable(keysOut.ptr, orderOut.ptr, points.ptr, n, tracer->slotKey.ptr, tracer->slotStart.ptr,
+                          tracer->slotCount.ptr, slots - 1, tracer->probePoints.ptr, stream);
+
+    // the 27-neighbour filter: candidate keys, sorted, runs merged
+    const uint64_t candidates = 27 * cellCount;
+    DeviceArray<unsigned long long> nearIn, nearOut;
+    DeviceArray<uint32_t> bitsIn, bitsOut;
+    nearIn.allocate(candidates);
+    nearOut.allocate(candidates);
+    bitsIn.allocate(candidates);
+    bitsOut.allocate(candidates);
+    rtd::launchNeighbourKeys(keysOut.ptr, n, nearIn.ptr, bitsIn.ptr, scalars.ptr + 1, stream);
+    bytes = rtd::sortKeyPairs(nullptr, 0, nearIn.ptr, nearOut.ptr, bitsIn.ptr, bitsOut.ptr, candidates, stream);
+    if (scratch.count < bytes) scratch.allocate(bytes);
+    rtd::sortKeyPairs(scratch.ptr, bytes, nearIn.ptr, nearOut.ptr, bitsIn.ptr, bitsOut.ptr, candidates, stream);
+    check(hipMemsetAsync(scalars.ptr, 0, sizeof(unsigned long long), stream), "hipMemsetAsync");
+    rtd::launchCountRuns(nearOut.ptr, candidates, scalars.ptr, stream);
+    unsigned long long nearCount = 0;
+    check(hipMemcpyAsync(&nearCount, scalars.ptr, sizeof(nearCount), hipMemcpyDeviceToHost, stream), "hipMemcpyAsync runs");
+    check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+    uint64_t nearSlots = 16;
+    while (nearSlots < 2 * nearCount + 1)
+    {
+        nearSlots <<= 1;
+    }
+    tracer->nearKey.allocate(nearSlots);
+    tracer->nearBits.allocate(nearSlots);
+    check(hipMemsetAsync(tracer->nearKey.ptr, 0xFF, nearSlots * sizeof(unsigned long long), stream), "hipMemsetAsync");
+    tracer->nearBits.zero(stream);
+    rtd::launchNeighbourTable(nearOut.ptr, bitsOut.ptr, candidates, tracer->nearKey.ptr, tracer->nearBits.ptr,
+                              nearSlots - 1, stream);
+    check(hipGetLastError(), "probe grid build");
+    check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+
+    rtd::ProbeView& pv = tracer->probeView;
+    pv.slotKey = tracer->slotKey.ptr;
+    pv.slotStart = tracer->slotStart.ptr;
+    pv.slotCount = tracer->slotCount.ptr;
+    pv.points = tracer->probePoints.ptr;
+    pv.slotMask = slots - 1;
+    pv.probeCount = n;
+    pv.invCellSize = invCellSize;
+    pv.keepRadius = keepRadius;
+    pv.reach = reach;
+    pv.nearKey = tracer->nearKey.ptr;
+    pv.nearBits = tracer->nearBits.ptr;
+    pv.nearMask = nearSlots - 1;
+    return true;
+}
+
 template <typename F>
 int32_t guarded(F&& body)
 {
@@ -685,6 +787,14 @@ int32_t rt_set_probes(rt_tracer* tracer, const double* probes, uint64_t n, doubl
         const double cellSize = cell_size > 0.0 ? cell_size : 1.0;
         const double invCellSize = 1.0 / cellSize;
         const double keepRadius = keep_radius > 0.0 ? keep_radius : 0.0;
+        tracer->storeCapacity = store_capacity;
+        tracer->storeRecords.allocate(static_cast<size_t>(store_capacity) * 13);
+        // the usual case (one cell of reach, coordinates that pack) is built on the device
+        if (buildProbesOnDevice(tracer, probes, n, invCellSize, keepRadius))
+        {
+            tracer->probesSet = true;
+            return;
+        }
         std::map<CellKey, std::vector<uint32_t>> cells;
         for (uint64_t i = 0; i < n; ++i)
         {
@@ -796,8 +906,6 @@ int32_t rt_set_probes(rt_tracer* tracer, const double* probes, uint64_t n, doubl
             pv.nearBits = tracer->nearBits.ptr;
             pv.nearMask = nearSlots - 1;
         }
-        tracer->storeCapacity = store_capacity;
-        tracer->storeRecords.allocate(static_cast<size_t>(store_capacity) * 13);
         tracer->probesSet = true;
     });
 }

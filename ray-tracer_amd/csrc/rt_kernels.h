@@ -134,6 +134,27 @@ size_t sortStoreKeys(void* scratch, size_t scratchBytes, const unsigned long lon
                      unsigned long long* keysOut, const uint32_t* orderIn, uint32_t* orderOut, uint64_t n,
                      hipStream_t stream);
 void launchGather(const GatherArgs& args, hipStream_t stream);
+// Device-side build of the probe grid (rt_set_probes): see the kernels in rt_kernels.hip.
+struct ProbeBuild
+{
+    const double* points;          // [n][3] as given by the caller
+    uint64_t n;
+    double invCellSize;
+    unsigned long long* keys;      // [n] packed cell of each probe (kEmptyKey: does not pack)
+    uint32_t* order;               // [n] probe index
+};
+void launchProbeKeys(const ProbeBuild& b, uint32_t* unpackable, hipStream_t stream);
+// stable ascending sort of (keys, order) pairs of any length below 2^31
+size_t sortKeyPairs(void* scratch, size_t scratchBytes, const unsigned long long* keysIn, unsigned long long* keysOut,
+                    const uint32_t* orderIn, uint32_t* orderOut, uint64_t n, hipStream_t stream);
+void launchCountRuns(const unsigned long long* sortedKeys, uint64_t n, unsigned long long* runs, hipStream_t stream);
+void launchProbeTable(const unsigned long long* sortedKeys, const uint32_t* sortedOrder, const double* points, uint64_t n,
+                      int64_t* slotKey, uint32_t* slotStart, uint32_t* slotCount, uint64_t slotMask,
+                      double* groupedPoints, hipStream_t stream);
+void launchNeighbourKeys(const unsigned long long* sortedKeys, uint64_t n, unsigned long long* outKeys,
+                         uint32_t* outBits, unsigned long long* cursor, hipStream_t stream);
+void launchNeighbourTable(const unsigned long long* sortedKeys, const uint32_t* sortedBits, uint64_t n,
+                          unsigned long long* nearKey, uint32_t* nearBits, uint64_t nearMask, hipStream_t stream);
 void launchProbeTest(const ProbeView& probes, int64_t n, const double* points, uint8_t* out, hipStream_t stream);
 
 }  // namespace rtd

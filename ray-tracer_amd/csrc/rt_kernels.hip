@@ -1266,6 +1266,140 @@ __global__ __launch_bounds__(kTileThreads) void emissionTileKernel(const TraceAr
     }
 }
 
+// ---------------------------------------------------------------- probe grid build
+// ProbeIndex's constructor (reference src/ProbeIndex.cpp:5-25) hashes every probe into an
+// unordered_map of cells.  Here the probes are keyed by packed cell, sorted, and the runs of
+// equal keys become the cells of an open-addressed table; the 27-neighbour occupancy filter
+// is built the same way from the 27 keys around every occupied cell.  x is packed in the high
+// bits as in the trace kernel's filter lookup.
+RT_DEV unsigned long long packProbeCell(int64_t x, int64_t y, int64_t z)
+{
+    return (static_cast<unsigned long long>(x + kPackLimit) << 42) | (static_cast<unsigned long long>(y + kPackLimit) << 21) |
+           static_cast<unsigned long long>(z + kPackLimit);
+}
+
+__global__ void probeKeysKernel(const ProbeBuild b, uint32_t* unpackable)
+{
+    const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= b.n) return;
+    const int64_t x = static_cast<int64_t>(__builtin_floor(b.points[3 * i + 0] * b.invCellSize));
+    const int64_t y = static_cast<int64_t>(__builtin_floor(b.points[3 * i + 1] * b.invCellSize));
+    const int64_t z = static_cast<int64_t>(__builtin_floor(b.points[3 * i + 2] * b.invCellSize));
+    const int64_t lim = kPackLimit - 2;  // leaves room for the neighbours of a border cell
+    const bool fits = x > -lim && x < lim && y > -lim && y < lim && z > -lim && z < lim;
+    if (!fits)
+    {
+        atomicAdd(unpackable, 1u);
+    }
+    b.keys[i] = fits ? packProbeCell(x, y, z) : kEmptyKey;
+    b.order[i] = static_cast<uint32_t>(i);
+}
+
+// runs[0] += number of runs of equal keys (= occupied cells)
+__global__ void countRunsKernel(const unsigned long long* keys, uint64_t n, unsigned long long* runs)
+{
+    const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const bool head = i < n && (i == 0 || keys[i] != keys[i - 1]);
+    const unsigned long long mask = __ballot(head);
+    if ((threadIdx.x & 63) == 0 && mask != 0)
+    {
+        atomicAdd(runs, static_cast<unsigned long long>(__builtin_popcountll(mask)));
+    }
+}
+
+// every probe is copied to its place in cell order; the first probe of every cell enters the
+// cell into the table (a slot is claimed through its count, 0 = free)
+__global__ void probeTableKernel(const unsigned long long* keys, const uint32_t* order, const double* points, uint64_t n,
+                                 int64_t* slotKey, uint32_t* slotStart, uint32_t* slotCount, uint64_t slotMask,
+                                 double* grouped)
+{
+    const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t src = order[i];
+    grouped[3 * i + 0] = points[3 * static_cast<uint64_t>(src) + 0];
+    grouped[3 * i + 1] = points[3 * static_cast<uint64_t>(src) + 1];
+    grouped[3 * i + 2] = points[3 * static_cast<uint64_t>(src) + 2];
+    const unsigned long long key = keys[i];
+    if (i != 0 && keys[i - 1] == key)
+    {
+        return;
+    }
+    uint32_t count = 1;
+    while (i + count < n && keys[i + count] == key)
+    {
+        count += 1;
+    }
+    const int64_t x = static_cast<int64_t>(key >> 42) - kPackLimit;
+    const int64_t y = static_cast<int64_t>((key >> 21) & ((1ull << 21) - 1)) - kPackLimit;
+    const int64_t z = static_cast<int64_t>(key & ((1ull << 21) - 1)) - kPackLimit;
+    uint64_t slot = cellHash(x, y, z) & slotMask;
+    while (atomicCAS(slotCount + slot, 0u, count) != 0u)
+    {
+        slot = (slot + 1) & slotMask;
+    }
+    slotKey[3 * slot + 0] = x;
+    slotKey[3 * slot + 1] = y;
+    slotKey[3 * slot + 2] = z;
+    slotStart[slot] = static_cast<uint32_t>(i);
+}
+
+// for every occupied cell, the 27 cells around it, each with the bit that says "my neighbour
+// at the opposite offset is occupied"
+__global__ void neighbourKeysKernel(const unsigned long long* keys, uint64_t n, unsigned long long* outKeys,
+                                    uint32_t* outBits, unsigned long long* cursor)
+{
+    const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const bool head = i < n && (i == 0 || keys[i] != keys[i - 1]);
+    const unsigned long long mask = __ballot(head);
+    if (mask == 0) return;
+    unsigned long long base = 0;
+    const int leader = __builtin_ctzll(mask);
+    if (static_cast<int>(threadIdx.x & 63) == leader)
+    {
+        base = atomicAdd(cursor, 27ull * static_cast<unsigned long long>(__builtin_popcountll(mask)));
+    }
+    base = __shfl(base, leader, 64);
+    if (!head) return;
+    const unsigned long long at = base + 27ull * lanesBelow(mask);
+    const unsigned long long key = keys[i];
+    const int64_t x = static_cast<int64_t>(key >> 42) - kPackLimit;
+    const int64_t y = static_cast<int64_t>((key >> 21) & ((1ull << 21) - 1)) - kPackLimit;
+    const int64_t z = static_cast<int64_t>(key & ((1ull << 21) - 1)) - kPackLimit;
+    int k = 0;
+    for (int dz = -1; dz <= 1; ++dz)
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx)
+            {
+                outKeys[at + k] = packProbeCell(x + dx, y + dy, z + dz);
+                outBits[at + k] = 1u << ((1 - dz) * 9 + (1 - dy) * 3 + (1 - dx));
+                k += 1;
+            }
+}
+
+// sorted neighbour keys: the first of every run ORs the run's bits and enters the table
+__global__ void neighbourTableKernel(const unsigned long long* keys, const uint32_t* bits, uint64_t n,
+                                     unsigned long long* nearKey, uint32_t* nearBits, uint64_t nearMask)
+{
+    const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long key = keys[i];
+    if (i != 0 && keys[i - 1] == key) return;
+    uint32_t all = 0;
+    for (uint64_t j = i; j < n && keys[j] == key; ++j)
+    {
+        all |= bits[j];
+    }
+    const int64_t x = static_cast<int64_t>(key >> 42) - kPackLimit;
+    const int64_t y = static_cast<int64_t>((key >> 21) & ((1ull << 21) - 1)) - kPackLimit;
+    const int64_t z = static_cast<int64_t>(key & ((1ull << 21) - 1)) - kPackLimit;
+    uint64_t slot = cellHash(x, y, z) & nearMask;
+    while (atomicCAS(nearKey + slot, kEmptyKey, key) != kEmptyKey)
+    {
+        slot = (slot + 1) & nearMask;
+    }
+    nearBits[slot] = all;
+}
+
 int gridFor(int64_t n) { return static_cast<int>((n + 255) / 256); }
 
 // dynamic LDS of a kernel that casts rays: one traversal stack per lane
@@ -1402,6 +1536,52 @@ void launchGather(const GatherArgs& args, hipStream_t stream)
 {
     if (args.pixels <= 0) return;
     hipLaunchKernelGGL(gatherKernel, dim3(gridFor(args.pixels)), dim3(256), 0, stream, args);
+}
+
+void launchProbeKeys(const ProbeBuild& b, uint32_t* unpackable, hipStream_t stream)
+{
+    if (b.n == 0) return;
+    hipLaunchKernelGGL(probeKeysKernel, dim3(gridFor(static_cast<int64_t>(b.n))), dim3(256), 0, stream, b, unpackable);
+}
+
+size_t sortKeyPairs(void* scratch, size_t scratchBytes, const unsigned long long* keysIn, unsigned long long* keysOut,
+                    const uint32_t* orderIn, uint32_t* orderOut, uint64_t n, hipStream_t stream)
+{
+    size_t bytes = scratchBytes;
+    (void)hipcub::DeviceRadixSort::SortPairs(scratch, bytes, keysIn, keysOut, orderIn, orderOut, static_cast<int>(n), 0,
+                                             64, stream);
+    return bytes;
+}
+
+void launchCountRuns(const unsigned long long* sortedKeys, uint64_t n, unsigned long long* runs, hipStream_t stream)
+{
+    if (n == 0) return;
+    hipLaunchKernelGGL(countRunsKernel, dim3(gridFor(static_cast<int64_t>(n))), dim3(256), 0, stream, sortedKeys, n, runs);
+}
+
+void launchProbeTable(const unsigned long long* sortedKeys, const uint32_t* sortedOrder, const double* points, uint64_t n,
+                      int64_t* slotKey, uint32_t* slotStart, uint32_t* slotCount, uint64_t slotMask,
+                      double* groupedPoints, hipStream_t stream)
+{
+    if (n == 0) return;
+    hipLaunchKernelGGL(probeTableKernel, dim3(gridFor(static_cast<int64_t>(n))), dim3(256), 0, stream, sortedKeys, sortedOrder,
+                       points, n, slotKey, slotStart, slotCount, slotMask, groupedPoints);
+}
+
+void launchNeighbourKeys(const unsigned long long* sortedKeys, uint64_t n, unsigned long long* outKeys,
+                         uint32_t* outBits, unsigned long long* cursor, hipStream_t stream)
+{
+    if (n == 0) return;
+    hipLaunchKernelGGL(neighbourKeysKernel, dim3(gridFor(static_cast<int64_t>(n))), dim3(256), 0, stream, sortedKeys, n, outKeys,
+                       outBits, cursor);
+}
+
+void launchNeighbourTable(const unsigned long long* sortedKeys, const uint32_t* sortedBits, uint64_t n,
+                          unsigned long long* nearKey, uint32_t* nearBits, uint64_t nearMask, hipStream_t stream)
+{
+    if (n == 0) return;
+    hipLaunchKernelGGL(neighbourTableKernel, dim3(gridFor(static_cast<int64_t>(n))), dim3(256), 0, stream, sortedKeys, sortedBits,
+                       n, nearKey, nearBits, nearMask);
 }
 
 void launchProbeTest(const ProbeView& probes, int64_t n, const double* points, uint8_t* out, hipStream_t stream)
