@@ -1,0 +1,98 @@
+"""Image-equivalence measures for frames of the same scene at equal photon count.
+
+`noise_metric` restates the reference's scripts/noise_metric.py:1-86 (full-image mean
+luminance, and mean / coefficient of variation over a flat region, on sRGB-linearised
+Rec.709 luma of the 8-bit image); `rel_rmse` is the relative RMSE of two linear float
+buffers.  Usage:  python -m ray-tracer_amd.image_check a.png b.png
+"""
+import struct
+import sys
+import zlib
+
+import numpy as np
+
+DEFAULT_REGION = (0.40, 0.20, 0.60, 0.38)  # flat back-wall patch, reference scripts/noise_metric.py:83-85
+
+
+def read_png16(path):
+    """Decode a non-interlaced 16-bit RGB PNG with filter type 0 rows (what PngWriter emits)
+    or any filter, into uint16 [h, w, 3]."""
+    data = open(path, "rb").read()
+    if data[:8] != b"\x89PNG\r\n\x1a\n":
+        raise ValueError(f"{path}: not a PNG")
+    at, idat, header = 8, b"", None
+    while at < len(data):
+        (n,), kind = struct.unpack(">I", data[at:at + 4]), data[at + 4:at + 8]
+        body = data[at + 8:at + 8 + n]
+        if kind == b"IHDR":
+            header = struct.unpack(">IIBBBBB", body)
+        elif kind == b"IDAT":
+            idat += body
+        at += 12 + n
+    w, h, depth, colour, _, _, interlace = header
+    if (depth, colour, interlace) != (16, 2, 0):
+        raise ValueError(f"{path}: expected 16-bit RGB, non-interlaced")
+    raw = np.frombuffer(zlib.decompress(idat), dtype=np.uint8).reshape(h, 1 + w * 6).astype(np.int32)
+    stride, bpp = w * 6, 6
+    out = np.zeros((h, stride), dtype=np.int32)
+    for y in range(h):
+        f, line = raw[y, 0], raw[y, 1:]
+        prev = out[y - 1] if y else np.zeros(stride, dtype=np.int32)
+        if f == 0:
+            out[y] = line
+        elif f == 2:
+            out[y] = (line + prev) & 255
+        else:  # sub, average, paeth need the running left neighbour
+            row = np.zeros(stride, dtype=np.int32)
+            for x in range(stride):
+                a = row[x - bpp] if x >= bpp else 0
+                b = prev[x]
+                c = prev[x - bpp] if x >= bpp else 0
+                if f == 1:
+                    pred = a
+                elif f == 3:
+                    pred = (a + b) // 2
+                else:
+                    p = a + b - c
+                    pa, pb, pc = abs(p - a), abs(p - b), abs(p - c)
+                    pred = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+                row[x] = (line[x] + pred) & 255
+            out[y] = row
+    return out.astype(np.uint8).view(">u2").reshape(h, w, 3).astype(np.uint16)
+
+
+def noise_metric(image16, region=DEFAULT_REGION):
+    """(full-image mean luminance, flat-region mean, flat-region std / mean) of a uint16 [h, w, 3] image."""
+    c = (image16 >> 8).astype(np.float64) / 255.0  # the 8-bit image the reference script reads
+    linear = np.where(c <= 0.04045, c / 12.92, ((c + 0.055) / 1.055) ** 2.4)
+    luma = 0.2126 * linear[..., 0] + 0.7152 * linear[..., 1] + 0.0722 * linear[..., 2]
+    h, w = luma.shape
+    x0, y0, x1, y1 = int(region[0] * w), int(region[1] * h), int(region[2] * w), int(region[3] * h)
+    patch = luma[y0:y1, x0:x1]
+    mean = float(patch.mean()) if patch.size else 0.0
+    std = float(patch.std()) if patch.size else 0.0
+    return float(luma.mean()), mean, (std / mean if mean > 0 else 0.0)
+
+
+def rel_rmse(got, want):
+    """sqrt(mean((got - want)^2)) / mean(|want|) over linear float buffers of equal shape."""
+    got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
+    scale = np.abs(want).mean()
+    return float(np.sqrt(((got - want) ** 2).mean()) / scale) if scale > 0 else float(np.abs(got).max())
+
+
+def main(argv):
+    if len(argv) < 2:
+        print(__doc__)
+        return 1
+    images = [read_png16(p) for p in argv[1:3]]
+    for p, im in zip(argv[1:3], images):
+        full, mean, cov = noise_metric(im)
+        print(f"{p}: full-image mean luminance {full:.6f}; flat region mean {mean:.6f} cov {cov:.4f}")
+    if len(images) == 2 and images[0].shape == images[1].shape:
+        print(f"relative RMSE of the 16-bit images: {rel_rmse(images[0], images[1]):.3e}")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main(sys.argv))

@@ -9,8 +9,12 @@ import zlib
 import numpy as np
 import pytest
 
+import importlib
+
 import oracle_lib as O
 from conftest import REPO
+
+image_check = importlib.import_module("ray-tracer_amd.image_check")
 
 CLI = os.path.join(REPO, "ray-tracer_amd", "host", "ray-tracer")
 
@@ -112,3 +116,39 @@ def test_cli_renders_frame_equal_to_oracle(rt, tmp_path, probe_gather):
             iso, shutter, f_number = cam.iso, cam.shutter_time, cam.f_number
             saturation = (f_number * f_number * 12.5) / (shutter * iso) if shutter * iso > 0 else 0.0
             assert np.array_equal(image, O.tonemap(got, saturation))
+
+
+@pytest.mark.gpu
+def test_cornell_box_image_equivalence(rt, tmp_path):
+    """Image equivalence at equal photon count on a BASELINE configuration (CornellBox.json,
+    reduced to 128 x 128 and 400 k photons so that the CPU oracle finishes in seconds): the
+    device frame and the oracle frame trace the same photons, so the linear buffers differ
+    only by float summation order.  Stated tolerances: relative RMSE <= 1e-5; the three
+    numbers of the reference's noise_metric.py equal to 1e-4 relative."""
+    scene = json.load(open(os.path.join(REPO, "scenes", "CornellBox.json")))
+    scene["$renderConfiguration"].update({"$width": 128, "$height": 128, "$photonsPerLight": 400000, "$seed": 5,
+                                          "$renderPath": str(tmp_path / "out"), "$renderName": "cornell"})
+    path = tmp_path / "cornell.json"
+    path.write_text(json.dumps(scene))
+    r = run_cli(str(path), env=dict(os.environ, RT_DUMP_BUFFERS=str(tmp_path / "dump")))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    got = np.fromfile(tmp_path / "dump" / "camera0.f32", dtype=np.float32).reshape(128, 128, 3)
+    image = image_check.read_png16(tmp_path / "out" / "cornell.0.png")
+
+    loaded = rt.Scene(str(path))
+    orc = O.Oracle(loaded)
+    setup = O.frame_setup(orc, O.RNG_COUNTER, O.MATH_PORTABLE)
+    keep = setup["keep_radius"]
+    emitters, _ = orc.deposit_emitters(setup["probes"], keep, keep, setup["emitter_spacing"])
+    ref = orc.trace(rng_mode=O.RNG_COUNTER, math_mode=O.MATH_PORTABLE, sink_mode=O.SINK_PROBE, threads=8,
+                    probes=setup["probes"], probe_cell_size=keep, keep_radius=keep,
+                    store_capacity=setup["store_capacity"], preload=emitters)
+    want, _ = orc.gather(0, ref["store"], setup["gather_cell"], setup["min_gather_radius"])
+    assert float(want.mean()) > 0
+    assert image_check.rel_rmse(got, want) <= 1e-5
+    cam = loaded.desc.cameras[0]
+    saturation = (cam.f_number ** 2 * 12.5) / (cam.shutter_time * cam.iso)
+    metric_got = image_check.noise_metric(image)
+    metric_want = image_check.noise_metric(O.tonemap(want, saturation))
+    assert metric_want[0] > 0
+    np.testing.assert_allclose(metric_got, metric_want, rtol=1e-4)
