@@ -68,7 +68,7 @@ typedef struct rt_volume
     int32_t type;
     int32_t material;
     int32_t mesh;
-    int32_t reserved;
+    int32_t animation; /* 0 = static; otherwise 1 + index into rt_scene.animations */
     double position[3];
     double rotation[4];
     double param[18];
@@ -127,7 +127,7 @@ typedef struct rt_camera
     int32_t projection;
     int32_t bounce_filter; /* -1 = all (include/Camera.h) */
     int32_t light_filter;  /* -1 = all */
-    int32_t reserved;
+    int32_t animation;     /* 0 = static; otherwise 1 + index into rt_scene.animations */
     double orthographic_height;
     double aperture_radius; /* Camera::effectiveApertureRadius() */
     double focus_distance;
@@ -163,6 +163,37 @@ typedef struct rt_settings
     double shutter_time;
 } rt_settings;
 
+/* One keyframe of an animated property (reference include/Property.h:37-51).  Scalar
+ * tracks (rotation angle, radians) use component [0]. */
+typedef struct rt_keyframe
+{
+    double time;
+    double value[3];
+    double in_tangent[3];
+    double out_tangent[3];
+    int32_t use_auto_tangent; /* Catmull-Rom tangent from the neighbours (Property.h:161-186) */
+    int32_t reserved;
+} rt_keyframe;
+
+/* A keyframed object: KeyframedAnimationQuery::AnimatedObject (reference
+ * include/AnimationQuery.h:107-163).  At time t the object's WORLD transform is
+ *   position = position track at t (or constant_position when the track is empty)
+ *   rotation = has_rotation ? fromAxisAngle(rotation_axis, angle track at t) * base_rotation
+ *                           : base_rotation
+ * and replaces the scene-load transform (reference src/Volume.cpp:65-81,
+ * src/Camera.cpp:388-402).  Tracks are cubic Hermite splines, held outside their range
+ * (reference include/Property.h:95-156). */
+typedef struct rt_animation
+{
+    int32_t has_rotation;
+    int32_t reserved;
+    double rotation_axis[3];
+    double base_rotation[4];
+    double constant_position[3];
+    int64_t first_position_key, position_key_count; /* into rt_scene.keyframes */
+    int64_t first_rotation_key, rotation_key_count;
+} rt_animation;
+
 typedef struct rt_scene
 {
     int64_t volume_count;
@@ -179,6 +210,10 @@ typedef struct rt_scene
     rt_light* lights;
     rt_camera* cameras;
     rt_settings settings;
+    int64_t animation_count;
+    int64_t keyframe_count;
+    rt_animation* animations;
+    rt_keyframe* keyframes;
 } rt_scene;
 
 #ifdef __cplusplus

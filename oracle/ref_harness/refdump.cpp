@@ -267,7 +267,67 @@ BuiltScene build(const rt_scene& in)
         out.volumes.push_back(volume);
         out.volumeMesh.push_back(rv.type == RT_VOLUME_MESH ? rv.mesh : -1);
     }
+
+    // keyframed objects -> the reference's KeyframedAnimationQuery, keyed by object name
+    auto animatedObject = [&](const rt_animation& ra) {
+        KeyframedAnimationQuery::AnimatedObject a;
+        a.hasPosition = true;
+        a.position = Property<Vector>(vec(ra.constant_position));
+        for (int64_t k = 0; k < ra.position_key_count; ++k)
+        {
+            const rt_keyframe& rk = in.keyframes[ra.first_position_key + k];
+            Keyframe<Vector> key;
+            key.time = rk.time;
+            key.value = vec(rk.value);
+            key.inTangent = vec(rk.in_tangent);
+            key.outTangent = vec(rk.out_tangent);
+            key.useAutoTangent = rk.use_auto_tangent != 0;
+            a.position.addKeyframe(key);
+        }
+        a.hasRotation = ra.has_rotation != 0;
+        a.rotationAxis = vec(ra.rotation_axis);
+        for (int64_t k = 0; k < ra.rotation_key_count; ++k)
+        {
+            const rt_keyframe& rk = in.keyframes[ra.first_rotation_key + k];
+            Keyframe<double> key;
+            key.time = rk.time;
+            key.value = rk.value[0];
+            key.inTangent = rk.in_tangent[0];
+            key.outTangent = rk.out_tangent[0];
+            key.useAutoTangent = rk.use_auto_tangent != 0;
+            a.rotationAngle.addKeyframe(key);
+        }
+        a.baseRotation = quat(ra.base_rotation);
+        return a;
+    };
+    scene.animation = std::make_shared<KeyframedAnimationQuery>();
+    for (int64_t v = 0; v < in.volume_count; ++v)
+    {
+        if (in.volumes[v].animation > 0)
+        {
+            scene.animation->setObject("volume_" + std::to_string(v), animatedObject(in.animations[in.volumes[v].animation - 1]));
+        }
+    }
+    for (int64_t c = 0; c < in.camera_count; ++c)
+    {
+        if (in.cameras[c].animation > 0)
+        {
+            scene.animation->setObject(in.cameras[c].name, animatedObject(in.animations[in.cameras[c].animation - 1]));
+        }
+    }
     return out;
+}
+
+// The animation oracle a pass over `built` must use: the keyframed one when any object is
+// animated, else the static one (as Renderer::renderFrame chooses, src/Renderer.cpp:116-130).
+const AnimationQuery* animationOf(const BuiltScene& built)
+{
+    static StaticAnimationQuery fixed;
+    if (built.scene.animation && !built.scene.animation->empty())
+    {
+        return built.scene.animation.get();
+    }
+    return &fixed;
 }
 
 // ---------------------------------------------------------------- unit vectors
@@ -792,7 +852,7 @@ WalkOutput walk(BuiltScene& built, size_t recordPhotons, Worker* splatWorker)
                     size_t bestVolume = 0;
                     for (size_t v = 0; v < built.volumes.size(); ++v)
                     {
-                        std::optional<Hit> hit = built.volumes[v]->castRayAt(photon.ray, castBuffer, photon.time, nullptr);
+                        std::optional<Hit> hit = built.volumes[v]->castRayAt(photon.ray, castBuffer, photon.time, animationOf(built));
                         if (hit && hit->distance < minDistance && hit->distance > selfHit)
                         {
                             validHit = true;
@@ -897,6 +957,10 @@ int modeWalk(const std::string& scenePath, const std::string& dir, size_t record
     worker.camera = built.scene.camera;
     worker.objects = built.scene.objects;
     worker.materialLibrary = built.scene.materialLibrary;
+    if (built.scene.animation && !built.scene.animation->empty())
+    {
+        worker.animationQuery = built.scene.animation;  // the splat's occlusion cast sees the photon's time
+    }
     worker.setPhotonsPerLight(static_cast<double>(built.scene.settings.photonsPerLight));
     worker.setMinSplatRadius(d.minSplatRadius);
     worker.setSplatLuminanceClamp(built.scene.settings.splatLuminanceClamp);
@@ -995,12 +1059,11 @@ int modeProbes(const std::string& scenePath, const std::string& dir)
     BuiltScene built = build(in);
     setExposureWindows(built);
     const RenderSettings& s = built.scene.settings;
-    StaticAnimationQuery animation;
     for (size_t c = 0; c < built.scene.cameras.size(); ++c)
     {
         const auto t0 = std::chrono::steady_clock::now();
         ProbeGather::ProbeResult r = ProbeGather::collectGatherPoints(
-            built.scene.objects, *built.scene.cameras[c], *built.scene.materialLibrary, &animation,
+            built.scene.objects, *built.scene.cameras[c], *built.scene.materialLibrary, animationOf(built),
             static_cast<float>(s.frameTime), static_cast<float>(s.shutterTime), s.cameraTimeSamples,
             s.probeSubSample, probeSeedFor(s));
         const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -1100,14 +1163,13 @@ int modeRender(const std::string& scenePath, const std::string& dir)
             BuiltScene again = build(in);
             setExposureWindows(again);
             const Derived d = derive(again);
-            StaticAnimationQuery animation;
             std::vector<Vector> probes;
             for (const auto& cam : again.scene.cameras)
             {
                 if (cam->bounceFilter() >= 0 || cam->lightFilter() >= 0) continue;
                 const RenderSettings& s = again.scene.settings;
                 ProbeGather::ProbeResult r = ProbeGather::collectGatherPoints(
-                    again.scene.objects, *cam, *again.scene.materialLibrary, &animation,
+                    again.scene.objects, *cam, *again.scene.materialLibrary, animationOf(again),
                     static_cast<float>(s.frameTime), static_cast<float>(s.shutterTime), s.cameraTimeSamples,
                     s.probeSubSample, probeSeedFor(s));
                 for (const auto& gp : r.points) probes.push_back(gp.position);

@@ -708,6 +708,8 @@ uint64_t rt_abi_struct_size(int32_t which)
         case 6: return sizeof(rt_settings);
         case 7: return sizeof(rt_counters);
         case 8: return sizeof(rt_trace_params);
+        case 9: return sizeof(rt_animation);
+        case 10: return sizeof(rt_keyframe);
         default: return 0;
     }
 }

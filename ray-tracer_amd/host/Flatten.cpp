@@ -44,7 +44,73 @@ void FlatScene::bind()
     scene.materials = materials.data();
     scene.lights = lights.data();
     scene.cameras = cameras.data();
+    scene.animation_count = static_cast<int64_t>(animations.size());
+    scene.keyframe_count = static_cast<int64_t>(keyframes.size());
+    scene.animations = animations.data();
+    scene.keyframes = keyframes.data();
 }
+
+namespace
+{
+
+// 1 + index of the object's animation in out.animations, 0 when the object is static
+int32_t animationOf(const LoadedScene& loaded, const std::string& name, FlatScene& out,
+                    std::map<std::string, int32_t>& seen)
+{
+    const auto it = loaded.animation.find(name);
+    if (it == loaded.animation.end())
+    {
+        return 0;
+    }
+    const auto known = seen.find(name);
+    if (known != seen.end())
+    {
+        return known->second;
+    }
+    const AnimatedObject& a = it->second;
+    rt_animation ra{};
+    ra.has_rotation = a.hasRotation ? 1 : 0;
+    ra.rotation_axis[0] = a.rotationAxis.x;
+    ra.rotation_axis[1] = a.rotationAxis.y;
+    ra.rotation_axis[2] = a.rotationAxis.z;
+    ra.base_rotation[0] = a.baseRotation.x;
+    ra.base_rotation[1] = a.baseRotation.y;
+    ra.base_rotation[2] = a.baseRotation.z;
+    ra.base_rotation[3] = a.baseRotation.w;
+    ra.constant_position[0] = a.constantPosition.x;
+    ra.constant_position[1] = a.constantPosition.y;
+    ra.constant_position[2] = a.constantPosition.z;
+    ra.first_position_key = static_cast<int64_t>(out.keyframes.size());
+    ra.position_key_count = static_cast<int64_t>(a.position.size());
+    for (const Keyframe<Vector>& k : a.position)
+    {
+        rt_keyframe rk{};
+        rk.time = k.time;
+        rk.value[0] = k.value.x; rk.value[1] = k.value.y; rk.value[2] = k.value.z;
+        rk.in_tangent[0] = k.inTangent.x; rk.in_tangent[1] = k.inTangent.y; rk.in_tangent[2] = k.inTangent.z;
+        rk.out_tangent[0] = k.outTangent.x; rk.out_tangent[1] = k.outTangent.y; rk.out_tangent[2] = k.outTangent.z;
+        rk.use_auto_tangent = k.useAutoTangent ? 1 : 0;
+        out.keyframes.push_back(rk);
+    }
+    ra.first_rotation_key = static_cast<int64_t>(out.keyframes.size());
+    ra.rotation_key_count = static_cast<int64_t>(a.rotationAngle.size());
+    for (const Keyframe<double>& k : a.rotationAngle)
+    {
+        rt_keyframe rk{};
+        rk.time = k.time;
+        rk.value[0] = k.value;
+        rk.in_tangent[0] = k.inTangent;
+        rk.out_tangent[0] = k.outTangent;
+        rk.use_auto_tangent = k.useAutoTangent ? 1 : 0;
+        out.keyframes.push_back(rk);
+    }
+    out.animations.push_back(ra);
+    const int32_t id = static_cast<int32_t>(out.animations.size());
+    seen[name] = id;
+    return id;
+}
+
+}  // namespace
 
 void flattenScene(const LoadedScene& loaded, FlatScene& out)
 {
@@ -89,6 +155,7 @@ void flattenScene(const LoadedScene& loaded, FlatScene& out)
     }
 
     // meshes, library order; volumes refer to them by index
+    std::map<std::string, int32_t> animationIds;
     std::map<const Mesh*, int32_t> meshIndex;
     if (loaded.meshLibrary)
     {
@@ -121,6 +188,7 @@ void flattenScene(const LoadedScene& loaded, FlatScene& out)
             rt_volume rv{};
             rv.material = static_cast<int32_t>(volume->materialIndex());
             rv.mesh = -1;
+            rv.animation = animationOf(loaded, object->name(), out, animationIds);
             put3(rv.position, volume->position());
             put4(rv.rotation, volume->rotation());
             if (auto mesh = std::dynamic_pointer_cast<MeshVolume>(object))
@@ -210,6 +278,7 @@ void flattenScene(const LoadedScene& loaded, FlatScene& out)
     for (const std::shared_ptr<Camera>& camera : loaded.cameras)
     {
         rt_camera rc{};
+        rc.animation = animationOf(loaded, camera->name(), out, animationIds);
         put3(rc.position, camera->position());
         put4(rc.rotation, camera->rotation());
         rc.vertical_fov_degrees = camera->verticalFieldOfView();

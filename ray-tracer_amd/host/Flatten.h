@@ -19,6 +19,8 @@ struct FlatScene
     std::vector<rt_material> materials;
     std::vector<rt_light> lights;
     std::vector<rt_camera> cameras;
+    std::vector<rt_animation> animations;
+    std::vector<rt_keyframe> keyframes;
 
     FlatScene() = default;
     FlatScene(const FlatScene&) = delete;

@@ -13,6 +13,7 @@
 #include <cstdint>
 #include <filesystem>
 #include <limits>
+#include <map>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -545,6 +546,29 @@ struct RenderSettings
     bool deterministic = false;
 };
 
+// ------------------------------------------------------------------ animation
+// reference include/Property.h:37-51 and include/AnimationQuery.h:107-163: keyframed world
+// position and spin angle of an object, keyed by object name.
+template <typename T>
+struct Keyframe
+{
+    double time = 0.0;
+    T value{};
+    T inTangent{};
+    T outTangent{};
+    bool useAutoTangent = true;
+};
+
+struct AnimatedObject
+{
+    std::vector<Keyframe<Vector>> position;   // empty: hold constantPosition
+    Vector constantPosition;                  // the object's scene-load (local) position
+    bool hasRotation = false;
+    Vector rotationAxis{0.0, 1.0, 0.0};
+    std::vector<Keyframe<double>> rotationAngle;  // radians about rotationAxis
+    Quaternion baseRotation;                  // the object's scene-load (local) rotation
+};
+
 struct LoadedScene
 {
     std::vector<std::shared_ptr<Object>> objects;
@@ -555,4 +579,5 @@ struct LoadedScene
     RenderSettings settings;
     std::filesystem::path renderPath;
     std::string renderName;
+    std::map<std::string, AnimatedObject> animation;  // by object name
 };

@@ -342,8 +342,92 @@ private:
 };
 
 // reference src/SceneLoader.cpp:717-746: parent first, then children in key order.
+// reference src/SceneLoader.cpp:202-254: {"t": seconds, "value": number | [x, y, z]} entries,
+// scalar tracks optionally with explicit per-second tangents.  Keyframes stay sorted by time
+// (a new key goes after the keys of equal time, reference include/Property.h:73-79).
+template <typename T>
+void insertKeyframe(std::vector<Keyframe<T>>& keys, const Keyframe<T>& key)
+{
+    auto at = std::upper_bound(keys.begin(), keys.end(), key,
+                               [](const Keyframe<T>& a, const Keyframe<T>& b) { return a.time < b.time; });
+    keys.insert(at, key);
+}
+
+void requireKeyframe(const Value& entry)
+{
+    if (!entry.isObject() || !entry.contains("t") || !entry.contains("value"))
+    {
+        throw std::runtime_error("Each keyframe must be an object with 't' and 'value'");
+    }
+}
+
+std::vector<Keyframe<double>> parseScalarKeyframes(const Value& list)
+{
+    if (!list.isArray())
+    {
+        throw std::runtime_error("$animation keyframe list must be an array");
+    }
+    std::vector<Keyframe<double>> keys;
+    for (const Value& entry : list.elements())
+    {
+        requireKeyframe(entry);
+        Keyframe<double> key;
+        key.time = entry.at("t").asDouble();
+        key.value = entry.at("value").asDouble();
+        if (entry.contains("inTangent") || entry.contains("outTangent"))
+        {
+            key.useAutoTangent = false;
+            key.inTangent = entry.contains("inTangent") ? entry.at("inTangent").asDouble() : 0.0;
+            key.outTangent = entry.contains("outTangent") ? entry.at("outTangent").asDouble() : 0.0;
+        }
+        insertKeyframe(keys, key);
+    }
+    return keys;
+}
+
+std::vector<Keyframe<Vector>> parseVectorKeyframes(const Value& list)
+{
+    if (!list.isArray())
+    {
+        throw std::runtime_error("$animation keyframe list must be an array");
+    }
+    std::vector<Keyframe<Vector>> keys;
+    for (const Value& entry : list.elements())
+    {
+        requireKeyframe(entry);
+        Keyframe<Vector> key;
+        key.time = entry.at("t").asDouble();
+        key.value = parseVectorFromJson(entry.at("value"));
+        insertKeyframe(keys, key);
+    }
+    return keys;
+}
+
+// reference src/SceneLoader.cpp:257-303
+AnimatedObject parseAnimationBlock(const Value& j, const Transform& loadTransform)
+{
+    AnimatedObject animated;
+    animated.baseRotation = loadTransform.rotation;
+    animated.constantPosition = loadTransform.position;
+    if (j.contains("$rotationAxis"))
+    {
+        animated.rotationAxis = parseVectorFromJson(j.at("$rotationAxis")).normalized();
+    }
+    if (j.contains("$rotation"))
+    {
+        animated.rotationAngle = parseScalarKeyframes(j.at("$rotation"));
+        animated.hasRotation = true;
+    }
+    if (j.contains("$position"))
+    {
+        animated.position = parseVectorKeyframes(j.at("$position"));
+    }
+    return animated;
+}
+
 std::vector<std::shared_ptr<Object>> parseObjectFromJson(const std::string& name, const Value& j,
-                                                         const std::shared_ptr<Object>& parent, ObjectFactory& factory)
+                                                         const std::shared_ptr<Object>& parent, ObjectFactory& factory,
+                                                         std::map<std::string, AnimatedObject>& animation)
 {
     std::vector<std::shared_ptr<Object>> parsed;
     std::shared_ptr<Object> object = factory.createObjectFromJson(j);
@@ -352,14 +436,13 @@ std::vector<std::shared_ptr<Object>> parseObjectFromJson(const std::string& name
     Object::setParent(object, parent);
     if (j.contains("$animation"))
     {
-        throw std::runtime_error("Object \"" + name +
-                                 "\": $animation is not supported by the GPU photon pass (static scenes only)");
+        animation[name] = parseAnimationBlock(j.at("$animation"), object->transform);
     }
     for (const auto& [childName, child] : j.items())
     {
         if (!childName.empty() && childName[0] != '$')
         {
-            auto children = parseObjectFromJson(childName, child, object, factory);
+            auto children = parseObjectFromJson(childName, child, object, factory, animation);
             parsed.insert(parsed.end(), children.begin(), children.end());
         }
     }
@@ -518,7 +601,7 @@ LoadedScene loadFromFile(const std::filesystem::path& scenePath, bool logToStdou
     {
         for (const auto& [name, object] : json.at("$scene").items())
         {
-            auto parsed = parseObjectFromJson(name, object, nullptr, factory);
+            auto parsed = parseObjectFromJson(name, object, nullptr, factory, scene.animation);
             scene.objects.insert(scene.objects.end(), parsed.begin(), parsed.end());
         }
     }

@@ -8,7 +8,7 @@ import ctypes as C
 
 class RtVolume(C.Structure):
     _fields_ = [
-        ("type", C.c_int32), ("material", C.c_int32), ("mesh", C.c_int32), ("reserved", C.c_int32),
+        ("type", C.c_int32), ("material", C.c_int32), ("mesh", C.c_int32), ("animation", C.c_int32),
         ("position", C.c_double * 3), ("rotation", C.c_double * 4), ("param", C.c_double * 18),
     ]
 
@@ -38,7 +38,7 @@ class RtCamera(C.Structure):
     _fields_ = [
         ("position", C.c_double * 3), ("rotation", C.c_double * 4), ("vertical_fov_degrees", C.c_double),
         ("width", C.c_int32), ("height", C.c_int32), ("projection", C.c_int32), ("bounce_filter", C.c_int32),
-        ("light_filter", C.c_int32), ("reserved", C.c_int32), ("orthographic_height", C.c_double),
+        ("light_filter", C.c_int32), ("animation", C.c_int32), ("orthographic_height", C.c_double),
         ("aperture_radius", C.c_double), ("focus_distance", C.c_double), ("f_number", C.c_double),
         ("shutter_time", C.c_double), ("iso", C.c_double), ("name", C.c_char * 64),
     ]
@@ -57,6 +57,22 @@ class RtSettings(C.Structure):
     ]
 
 
+class RtKeyframe(C.Structure):
+    _fields_ = [
+        ("time", C.c_double), ("value", C.c_double * 3), ("in_tangent", C.c_double * 3),
+        ("out_tangent", C.c_double * 3), ("use_auto_tangent", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+class RtAnimation(C.Structure):
+    _fields_ = [
+        ("has_rotation", C.c_int32), ("reserved", C.c_int32), ("rotation_axis", C.c_double * 3),
+        ("base_rotation", C.c_double * 4), ("constant_position", C.c_double * 3),
+        ("first_position_key", C.c_int64), ("position_key_count", C.c_int64),
+        ("first_rotation_key", C.c_int64), ("rotation_key_count", C.c_int64),
+    ]
+
+
 class RtScene(C.Structure):
     _fields_ = [
         ("volume_count", C.c_int64), ("mesh_count", C.c_int64), ("triangle_count", C.c_int64),
@@ -64,4 +80,6 @@ class RtScene(C.Structure):
         ("volumes", C.POINTER(RtVolume)), ("meshes", C.POINTER(RtMesh)), ("tri_pos", C.POINTER(C.c_double)),
         ("tri_nrm", C.POINTER(C.c_double)), ("materials", C.POINTER(RtMaterial)), ("lights", C.POINTER(RtLight)),
         ("cameras", C.POINTER(RtCamera)), ("settings", RtSettings),
+        ("animation_count", C.c_int64), ("keyframe_count", C.c_int64),
+        ("animations", C.POINTER(RtAnimation)), ("keyframes", C.POINTER(RtKeyframe)),
     ]
