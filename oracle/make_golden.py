@@ -44,6 +44,12 @@ MANIFEST = {
     "render_mixed": {"scene": "tests/scenes/mixed.json", "photons_per_light": 2500, "fetch_size": 50000},
     "render_mixed_tight": {"scene": "tests/scenes/mixed.json", "photons_per_light": 2500, "fetch_size": 50000,
                            "probe_keep_radius_scale": 2.0},
+    # keyframed volumes and camera, half-second shutter starting at t = 0.3 s
+    "walk_animated": {"scene": "tests/scenes/animated.json", "photons_per_light": 300, "fetch_size": 120,
+                      "record": 1500, "frame_time": 0.3},
+    "probes_animated": {"scene": "tests/scenes/animated.json", "frame_time": 0.3},
+    "render_animated": {"scene": "tests/scenes/animated.json", "photons_per_light": 1500, "fetch_size": 50000,
+                        "frame_time": 0.3},
     "probes_bombardment": {"scene": "scenes/MirrorBombardment-200M.json", "image": 96, "probe_sub_sample": 1,
                            "seed": 11},
 }
@@ -67,6 +73,8 @@ def write_scene(rt, entry, path):
         s.fetch_size = entry["fetch_size"]
     if "seed" in entry:
         s.seeded, s.seed = 1, entry["seed"]
+    if "frame_time" in entry:
+        s.frame_time = entry["frame_time"]
     if "probe_keep_radius_scale" in entry:
         s.probe_keep_radius_scale = entry["probe_keep_radius_scale"]
     if "probe_sub_sample" in entry:
@@ -111,7 +119,7 @@ def main():
         np.savez_compressed(os.path.join(GOLDEN, "emit.npz"), **load_dir(d))
 
         # ---- photon walks ----
-        for key in ("walk_furnace", "walk_mixed"):
+        for key in ("walk_furnace", "walk_mixed", "walk_animated"):
             scene_path = os.path.join(tmp, key + ".rtsb")
             write_scene(rt, MANIFEST[key], scene_path)
             d = os.path.join(tmp, key)
@@ -133,7 +141,7 @@ def main():
         np.savez_compressed(os.path.join(GOLDEN, "render_furnace.npz"), **keep)
 
         # ---- whole frames in probe mode ----
-        for key in ("render_mixed", "render_mixed_tight"):
+        for key in ("render_mixed", "render_mixed_tight", "render_animated"):
             scene_path = os.path.join(tmp, key + ".rtsb")
             write_scene(rt, MANIFEST[key], scene_path)
             d = os.path.join(tmp, key)
@@ -149,7 +157,7 @@ def main():
             np.savez_compressed(os.path.join(GOLDEN, key + ".npz"), **keep)
 
         # ---- probe pass ----
-        for key in ("probes_mixed", "probes_bombardment"):
+        for key in ("probes_mixed", "probes_bombardment", "probes_animated"):
             scene_path = os.path.join(tmp, key + ".rtsb")
             write_scene(rt, MANIFEST[key], scene_path)
             d = os.path.join(tmp, key)

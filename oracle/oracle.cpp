@@ -547,6 +547,7 @@ struct Mesh
 struct Volume  // src/Volume.cpp:34-81
 {
     int type = 0, material = 0, mesh = -1;
+    int animation = -1;  // index into orc_context::animations, -1 = static
     Vec position;
     Quat rotation, inverseRotation;
     Vec sphereCenter;
@@ -583,6 +584,7 @@ struct Light
 struct Camera
 {
     rt_camera d{};
+    int animation = -1;  // index into orc_context::animations, -1 = static
     Vec position;
     Quat rotation;
     Vec right, up, forward;
@@ -1097,6 +1099,8 @@ struct orc_context
     std::vector<Material> materials;
     std::vector<Light> lights;
     std::vector<Camera> cameras;
+    std::vector<rt_animation> animations;
+    std::vector<rt_keyframe> keyframes;
 
     // results of the last trace
     std::vector<double> emitted, bounceF64;
@@ -1112,16 +1116,121 @@ struct orc_context
 namespace
 {
 
-Ray transformRay(const Volume& v, const Ray& ray)  // src/Volume.cpp:57-63
+// Which sin / cos the animation's axis-angle rotation uses on this thread: libm (the
+// reference's) or the portable pair shared with the device.  Set by the C entry points.
+thread_local bool tl_portableMath = false;
+
+// Property<T>::evaluate, include/Property.h:95-213: cubic Hermite through the keyframes with
+// Catmull-Rom tangents where none are given, held outside the keyed range.  `dims` is 1 for
+// the angle track and 3 for the position track.
+void evaluateTrack(const rt_keyframe* keys, std::int64_t n, int dims, double t, double out[3])
 {
-    return {rotate(v.inverseRotation, ray.origin - v.position), rotate(v.inverseRotation, ray.direction)};
+    auto value = [&](std::int64_t i, int d) { return keys[i].value[d]; };
+    auto hold = [&](std::int64_t i) {
+        for (int d = 0; d < dims; ++d) out[d] = value(i, d);
+    };
+    if (n == 1 || t <= keys[0].time)
+    {
+        hold(0);
+        return;
+    }
+    if (t >= keys[n - 1].time)
+    {
+        hold(n - 1);
+        return;
+    }
+    std::int64_t idx = 1;
+    while (idx < n && keys[idx].time <= t)
+    {
+        ++idx;
+    }
+    const rt_keyframe& k0 = keys[idx - 1];
+    const rt_keyframe& k1 = keys[idx];
+    const double dt = k1.time - k0.time;
+    if (dt <= 0.0)
+    {
+        hold(idx - 1);
+        return;
+    }
+    const double s = (t - k0.time) / dt;
+    // autoTangent, include/Property.h:161-186
+    auto autoTangent = [&](std::int64_t i, int d) {
+        if (n < 2) return 0.0;
+        std::int64_t a = i - 1, b = i + 1;
+        if (i == 0) { a = 0; b = 1; }
+        else if (i == n - 1) { a = n - 2; b = n - 1; }
+        const double span = keys[b].time - keys[a].time;
+        if (span <= 0.0) return 0.0;
+        return (value(b, d) - value(a, d)) * (1.0 / span);
+    };
+    const double s2 = s * s;
+    const double s3 = s2 * s;
+    const double h00 = 2.0 * s3 - 3.0 * s2 + 1.0;
+    const double h10 = s3 - 2.0 * s2 + s;
+    const double h01 = -2.0 * s3 + 3.0 * s2;
+    const double h11 = s3 - s2;
+    for (int d = 0; d < dims; ++d)
+    {
+        const double m0 = k0.use_auto_tangent ? autoTangent(idx - 1, d) : k0.out_tangent[d];
+        const double m1 = k1.use_auto_tangent ? autoTangent(idx, d) : k1.in_tangent[d];
+        out[d] = k0.value[d] * h00 + m0 * (h10 * dt) + k1.value[d] * h01 + m1 * (h11 * dt);
+    }
 }
 
-// Volume::castRayAt, src/Volume.cpp:34-49.
-bool castVolume(const orc_context& ctx, int index, const Ray& ray, std::vector<Hit>& castBuffer, Hit& hit)
+struct Pose
+{
+    Vec position;
+    Quat rotation;
+};
+
+// KeyframedAnimationQuery::transformAt, include/AnimationQuery.h:130-158
+Pose poseAt(const orc_context& ctx, int animation, float time)
+{
+    const rt_animation& a = ctx.animations[animation];
+    const double t = static_cast<double>(time);
+    Pose pose;
+    pose.position = {a.constant_position[0], a.constant_position[1], a.constant_position[2]};
+    if (a.position_key_count > 0)
+    {
+        double p[3];
+        evaluateTrack(ctx.keyframes.data() + a.first_position_key, a.position_key_count, 3, t, p);
+        pose.position = {p[0], p[1], p[2]};
+    }
+    const Quat base{a.base_rotation[0], a.base_rotation[1], a.base_rotation[2], a.base_rotation[3]};
+    pose.rotation = base;
+    if (a.has_rotation)
+    {
+        double angle[3] = {0.0, 0.0, 0.0};  // an empty track is the constant 0 (Property<double>{})
+        if (a.rotation_key_count > 0)
+        {
+            evaluateTrack(ctx.keyframes.data() + a.first_rotation_key, a.rotation_key_count, 1, t, angle);
+        }
+        // Quaternion::fromAxisAngle, src/Quaternion.cpp:76-86
+        const double half = angle[0] / 2.0;
+        const double sa = tl_portableMath ? rt_sin(half) : std::sin(half);
+        const double ca = tl_portableMath ? rt_cos(half) : std::cos(half);
+        const Quat spin{a.rotation_axis[0] * sa, a.rotation_axis[1] * sa, a.rotation_axis[2] * sa, ca};
+        pose.rotation = spin * base;
+    }
+    return pose;
+}
+
+// Volume::castRayAt, src/Volume.cpp:34-81: the volume's world transform at the ray's time
+// (the keyframed pose when the volume is animated, else the scene-load transform), the ray
+// taken into object space, the hit taken back.
+bool castVolume(const orc_context& ctx, int index, const Ray& ray, float time, std::vector<Hit>& castBuffer, Hit& hit)
 {
     const Volume& v = ctx.volumes[index];
-    const Ray local = transformRay(v, ray);
+    Vec position = v.position;
+    Quat rotation = v.rotation, inverseRotation = v.inverseRotation;
+    if (v.animation >= 0)
+    {
+        const Pose pose = poseAt(ctx, v.animation, time);
+        position = pose.position;
+        rotation = pose.rotation;
+        inverseRotation = inverse(rotation);
+    }
+    const Ray local{rotate(inverseRotation, ray.origin - position), rotate(inverseRotation, ray.direction)};
     bool found = false;
     switch (v.type)
     {
@@ -1132,8 +1241,8 @@ bool castVolume(const orc_context& ctx, int index, const Ray& ray, std::vector<H
     }
     if (found)
     {
-        hit.position = v.position + rotate(v.rotation, hit.position);
-        hit.normal = rotate(v.rotation, hit.normal);
+        hit.position = position + rotate(rotation, hit.position);
+        hit.normal = rotate(rotation, hit.normal);
         hit.material = v.material;
         hit.volume = index;
         if (v.type != RT_VOLUME_MESH)
@@ -1145,14 +1254,15 @@ bool castVolume(const orc_context& ctx, int index, const Ray& ray, std::vector<H
 }
 
 // Nearest valid hit across all volumes, src/Worker.cpp:538-573 (also :314-333).
-bool castScene(const orc_context& ctx, const Ray& ray, double selfHit, std::vector<Hit>& castBuffer, Hit& best)
+bool castScene(const orc_context& ctx, const Ray& ray, float time, double selfHit, std::vector<Hit>& castBuffer,
+               Hit& best)
 {
     double minDistance = std::numeric_limits<double>::max();
     bool valid = false;
     for (size_t i = 0; i < ctx.volumes.size(); ++i)
     {
         Hit hit;
-        if (castVolume(ctx, static_cast<int>(i), ray, castBuffer, hit))
+        if (castVolume(ctx, static_cast<int>(i), ray, time, castBuffer, hit))
         {
             if (hit.distance < minDistance && hit.distance > selfHit)
             {
@@ -1240,7 +1350,7 @@ void splatToCamera(const TraceShared& sh, const Photon& photon, const Hit& hit, 
         if (cosCamera <= 0.0) continue;
 
         Hit occluder;
-        if (castScene(ctx, Ray{hit.position, toCameraDir}, kSelfHitThreshold, castBuffer, occluder) &&
+        if (castScene(ctx, Ray{hit.position, toCameraDir}, photon.time, kSelfHitThreshold, castBuffer, occluder) &&
             occluder.distance < cameraDistance)
         {
             continue;
@@ -1297,7 +1407,7 @@ void tracePhoton(const TraceShared& sh, Photon photon, std::uint64_t photonIndex
         }
         ++casts;
         Hit hit;
-        if (!castScene(ctx, photon.ray, kSelfHitThreshold, castBuffer, hit))
+        if (!castScene(ctx, photon.ray, photon.time, kSelfHitThreshold, castBuffer, hit))
         {
             break;
         }
@@ -1599,10 +1709,10 @@ bool intersectEmitterPatch(const EmitterPatch& patch, const Ray& ray, double& tO
 }
 
 // firstHit + firstEmitterHit, src/ProbeGather.cpp:57-127
-bool firstHit(const orc_context& ctx, const std::vector<EmitterPatch>& patches, const Ray& ray,
+bool firstHit(const orc_context& ctx, const std::vector<EmitterPatch>& patches, const Ray& ray, float time,
               std::vector<Hit>& castBuffer, Hit& closest)
 {
-    bool found = castScene(ctx, ray, kEps, castBuffer, closest);
+    bool found = castScene(ctx, ray, time, kEps, castBuffer, closest);
     if (!patches.empty())
     {
         double bestT = std::numeric_limits<double>::infinity();
@@ -1629,7 +1739,24 @@ bool firstHit(const orc_context& ctx, const std::vector<EmitterPatch>& patches, 
     return found;
 }
 
-// Camera::buildPrimaryRay, src/Camera.cpp:404-493 (static pose).
+// Camera::resolveEyeRotationAt, src/Camera.cpp:388-402: the camera with its eye and axes at `time`.
+Camera cameraAt(const orc_context& ctx, const Camera& cam, float time)
+{
+    if (cam.animation < 0)
+    {
+        return cam;
+    }
+    Camera posed = cam;
+    const Pose pose = poseAt(ctx, cam.animation, time);
+    posed.position = pose.position;
+    posed.rotation = pose.rotation;
+    posed.right = rotate(pose.rotation, kUnitX);
+    posed.up = rotate(pose.rotation, kUnitY);
+    posed.forward = rotate(pose.rotation, kUnitZ);
+    return posed;
+}
+
+// Camera::buildPrimaryRay, src/Camera.cpp:404-493.
 template <class M, class R>
 Ray buildPrimaryRay(const Camera& cam, size_t px, size_t py, R* rng)
 {
@@ -1683,13 +1810,13 @@ struct ExtendResult  // src/ProbeGather.cpp:138-147
 // src/ProbeGather.cpp:154-229
 template <class M, class R>
 ExtendResult extendAndRecord(const orc_context& ctx, const std::vector<EmitterPatch>& patches,
-                             std::vector<Hit>& castBuffer, R& rng, Ray ray)
+                             std::vector<Hit>& castBuffer, R& rng, Ray ray, float time)
 {
     ExtendResult out;
     for (int depth = 0; depth < kMaxSpecularDepth; ++depth)
     {
         Hit hit;
-        if (!firstHit(ctx, patches, ray, castBuffer, hit))
+        if (!firstHit(ctx, patches, ray, time, castBuffer, hit))
         {
             return out;
         }
@@ -1788,7 +1915,7 @@ struct GatherPoint  // include/ProbeGather.h:66-79
 // the pass-wide sequential stream in mt mode and the pixel's own Philox stream in counter
 // mode; `makeAdjacentRng` yields the fresh generator the adjacent-pixel walk uses (:411).
 template <class M, class R, class MakeAdj>
-void collectPixel(const orc_context& ctx, const Camera& cam, const std::vector<EmitterPatch>& patches, size_t px,
+void collectPixel(const orc_context& ctx, const Camera& staticCam, const std::vector<EmitterPatch>& patches, size_t px,
                   size_t py, R& rng, MakeAdj&& makeAdjacentRng, std::vector<Hit>& castBuffer,
                   std::vector<GatherPoint>& points, std::uint64_t counts[3])
 {
@@ -1796,20 +1923,22 @@ void collectPixel(const orc_context& ctx, const Camera& cam, const std::vector<E
     const float shutterSpan = std::max(0.0f, static_cast<float>(ctx.settings.shutter_time));
     const int cameraSamples = ctx.settings.camera_time_samples;
     const bool motionActive = (shutterSpan > 0.0f) && (cameraSamples > 1);
-    const bool dofActive = (cam.d.projection == RT_PROJECTION_REALLENS) && (cam.d.aperture_radius > 0.0);
+    const bool dofActive = (staticCam.d.projection == RT_PROJECTION_REALLENS) && (staticCam.d.aperture_radius > 0.0);
     const int motionSamples = motionActive ? cameraSamples : 1;
     const int dofSamples = dofActive ? kCameraSamplesPerPixel : 1;
     const int primarySamples = std::max(dofSamples, motionSamples);
-    const size_t width = static_cast<size_t>(cam.d.width);
+    const size_t width = static_cast<size_t>(staticCam.d.width);
     const size_t begin = points.size();
 
     for (int primary = 0; primary < primarySamples; ++primary)
     {
         const float sampleTime = motionActive ? frameTime + static_cast<float>(rng.value(shutterSpan)) : frameTime;
+        // Camera::generatePrimaryRayAt, src/Camera.cpp:375-402: an animated camera is posed at the sample's time
+        const Camera cam = cameraAt(ctx, staticCam, sampleTime);
         const Ray ray = dofActive ? buildPrimaryRay<M>(cam, px, py, &rng) : buildPrimaryRay<M, R>(cam, px, py, nullptr);
         ++counts[0];
         Hit first;
-        if (!firstHit(ctx, patches, ray, castBuffer, first))
+        if (!firstHit(ctx, patches, ray, sampleTime, castBuffer, first))
         {
             ++counts[2];
             continue;
@@ -1834,7 +1963,7 @@ void collectPixel(const orc_context& ctx, const Camera& cam, const std::vector<E
         const int extensionSamples = (stochasticDelta && !dofActive) ? kCameraSamplesPerPixel : 1;
         for (int ext = 0; ext < extensionSamples; ++ext)
         {
-            const ExtendResult chain = extendAndRecord<M>(ctx, patches, castBuffer, rng, ray);
+            const ExtendResult chain = extendAndRecord<M>(ctx, patches, castBuffer, rng, ray, sampleTime);
             if (chain.traversedDelta) ++counts[1];
             if (!chain.valid)
             {
@@ -1852,7 +1981,7 @@ void collectPixel(const orc_context& ctx, const Camera& cam, const std::vector<E
                     const Ray adjRay = dofActive ? buildPrimaryRay<M>(cam, adjX, py, &rng)
                                                  : buildPrimaryRay<M, R>(cam, adjX, py, nullptr);
                     auto adjRng = makeAdjacentRng();
-                    const ExtendResult adjChain = extendAndRecord<M>(ctx, patches, castBuffer, adjRng, adjRay);
+                    const ExtendResult adjChain = extendAndRecord<M>(ctx, patches, castBuffer, adjRng, adjRay, sampleTime);
                     if (adjChain.valid && adjChain.hit.material == chain.hit.material &&
                         dot(adjChain.hit.normal, chain.hit.normal) >= 0.5)
                     {
@@ -1942,6 +2071,8 @@ orc_context* orc_create(const rt_scene* scene)
     {
         auto ctx = std::make_unique<orc_context>();
         ctx->settings = scene->settings;
+        ctx->animations.assign(scene->animations, scene->animations + scene->animation_count);
+        ctx->keyframes.assign(scene->keyframes, scene->keyframes + scene->keyframe_count);
         for (std::int64_t m = 0; m < scene->mesh_count; ++m)
         {
             std::vector<Triangle> triangles;
@@ -1975,6 +2106,7 @@ orc_context* orc_create(const rt_scene* scene)
             v.position = {rv.position[0], rv.position[1], rv.position[2]};
             v.rotation = {rv.rotation[0], rv.rotation[1], rv.rotation[2], rv.rotation[3]};
             v.inverseRotation = inverse(v.rotation);
+            v.animation = rv.animation > 0 ? rv.animation - 1 : -1;
             if (rv.type == RT_VOLUME_SPHERE)
             {
                 v.sphereCenter = {rv.param[0], rv.param[1], rv.param[2]};
@@ -2024,6 +2156,7 @@ orc_context* orc_create(const rt_scene* scene)
         {
             Camera c;
             c.d = scene->cameras[i];
+            c.animation = c.d.animation > 0 ? c.d.animation - 1 : -1;
             c.position = {c.d.position[0], c.d.position[1], c.d.position[2]};
             c.rotation = {c.d.rotation[0], c.d.rotation[1], c.d.rotation[2], c.d.rotation[3]};
             c.right = rotate(c.rotation, kUnitX);
@@ -2093,6 +2226,7 @@ int orc_trace(orc_context* ctx, const orc_trace_config* config, orc_trace_result
     {
         std::memset(result, 0, sizeof(*result));
         orc_trace_config cfg = *config;
+        tl_portableMath = cfg.math_mode != ORC_MATH_LIBM;
         const std::uint64_t total = ctx->settings.photons_per_light;
         if (cfg.first_photon > total) cfg.first_photon = total;
         if (cfg.photon_count == 0 || cfg.first_photon + cfg.photon_count > total)
@@ -2167,6 +2301,7 @@ int orc_trace(orc_context* ctx, const orc_trace_config* config, orc_trace_result
                 const std::uint64_t lo = first + count * t / threads;
                 const std::uint64_t hi = first + count * (t + 1) / threads;
                 pool.emplace_back([&, lo, hi, t]() {
+                    tl_portableMath = cfg.math_mode != ORC_MATH_LIBM;
                     if (cfg.math_mode == ORC_MATH_LIBM) traceCounterRange<LibmMath>(sh, lo, hi, perThread[t]);
                     else traceCounterRange<PortableMath>(sh, lo, hi, perThread[t]);
                 });
@@ -2222,11 +2357,12 @@ void orc_cast_rays(const orc_context* ctx, std::int64_t n, const double* rays, d
                    std::int32_t* out_i32)
 {
     std::vector<Hit> castBuffer;
+    tl_portableMath = true;  // the function-level cast is compared with the device
     for (std::int64_t i = 0; i < n; ++i)
     {
         const Ray ray{{rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]}, {rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]}};
         Hit hit;
-        const bool found = castScene(*ctx, ray, self_hit, castBuffer, hit);
+        const bool found = castScene(*ctx, ray, static_cast<float>(ctx->settings.frame_time), self_hit, castBuffer, hit);
         double* f = out_f64 + 7 * i;
         std::int32_t* o = out_i32 + 4 * i;
         if (found)
@@ -2429,6 +2565,7 @@ std::int64_t orc_collect_gather_points(orc_context* ctx, std::int32_t camera, st
         return -1;
     }
     std::uint64_t counts[3] = {0, 0, 0};
+    tl_portableMath = math_mode != ORC_MATH_LIBM;
     const std::vector<GatherPoint> points = (math_mode == ORC_MATH_LIBM)
                                                 ? collectGatherPoints<LibmMath>(*ctx, camera, rng_mode, counts)
                                                 : collectGatherPoints<PortableMath>(*ctx, camera, rng_mode, counts);
@@ -2716,6 +2853,7 @@ std::int32_t orc_gather(orc_context* ctx, std::int32_t camera, std::int32_t rng_
         return 1;
     }
     std::uint64_t counts[3] = {0, 0, 0};
+    tl_portableMath = math_mode != ORC_MATH_LIBM;
     const std::vector<GatherPoint> points = (math_mode == ORC_MATH_LIBM)
                                                 ? collectGatherPoints<LibmMath>(*ctx, camera, rng_mode, counts)
                                                 : collectGatherPoints<PortableMath>(*ctx, camera, rng_mode, counts);

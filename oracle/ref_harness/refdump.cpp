@@ -747,7 +747,8 @@ Derived derive(const BuiltScene& built)
     return d;
 }
 
-int identifyTriangle(const BuiltScene& built, size_t volumeIndex, const Ray& worldRay, const Hit& hit, int& matches)
+int identifyTriangle(const BuiltScene& built, size_t volumeIndex, const Ray& worldRay, float time, const Hit& hit,
+                     int& matches)
 {
     matches = 0;
     const int mesh = built.volumeMesh[volumeIndex];
@@ -756,8 +757,16 @@ int identifyTriangle(const BuiltScene& built, size_t volumeIndex, const Ray& wor
         return -1;
     }
     const auto& volume = built.volumes[volumeIndex];
-    const Quaternion inv = volume->rotation().inverse();
-    const Ray local{inv * (worldRay.origin - volume->position()), inv * worldRay.direction};
+    // the pose Volume::castRayAt used for this ray (src/Volume.cpp:65-81): the animation's when there is one
+    Vector position = volume->position();
+    Quaternion rotation = volume->rotation();
+    if (const std::optional<Transform> moved = animationOf(built)->transformAt(volume->name(), time))
+    {
+        position = moved->position;
+        rotation = moved->rotation;
+    }
+    const Quaternion inv = rotation.inverse();
+    const Ray local{inv * (worldRay.origin - position), inv * worldRay.direction};
     int found = -1;
     const auto& triangles = built.meshTriangles[mesh];
     for (size_t t = 0; t < triangles.size(); ++t)
@@ -871,7 +880,7 @@ WalkOutput walk(BuiltScene& built, size_t recordPhotons, Worker* splatWorker)
                     if (record)
                     {
                         int matches = 0;
-                        const int tri = identifyTriangle(built, bestVolume, photon.ray, best, matches);
+                        const int tri = identifyTriangle(built, bestVolume, photon.ray, photon.time, best, matches);
                         push3(out.bounceF64, best.position);
                         push3(out.bounceF64, best.normal);
                         out.bounceF64.push_back(best.distance);
