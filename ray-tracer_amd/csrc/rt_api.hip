@@ -132,6 +132,8 @@ struct rt_tracer
     DeviceArray<rtd::Material> materials;
     DeviceArray<rtd::Light> lights;
     DeviceArray<rtd::Camera> cameras;
+    DeviceArray<rt_animation> animations;
+    DeviceArray<rt_keyframe> keyframes;
     std::vector<rtd::Camera> cameraHost;
     std::vector<std::unique_ptr<DeviceArray<float>>> cameraBuffers;
     std::vector<float*> boundBuffers;
@@ -258,6 +260,8 @@ void buildScene(rt_tracer* t, const rt_scene* scene)
         v.rot = rtd::Quat{rv.rotation[0], rv.rotation[1], rv.rotation[2], rv.rotation[3]};
         v.inv = quatInverse(v.rot);
         std::memcpy(v.param, rv.param, sizeof(v.param));
+        require(rv.animation >= 0 && rv.animation <= scene->animation_count, "volume animation index out of range");
+        v.animation = rv.animation - 1;  // the description counts from 1, 0 meaning static
         if (rv.type == RT_VOLUME_MESH)
         {
             require(rv.mesh >= 0 && rv.mesh < scene->mesh_count, "volume mesh index out of range");
@@ -348,6 +352,8 @@ void buildScene(rt_tracer* t, const rt_scene* scene)
         c.orthographicHeight = rc.orthographic_height;
         c.apertureRadius = rc.aperture_radius;
         c.focusDistance = rc.focus_distance;
+        require(rc.animation >= 0 && rc.animation <= scene->animation_count, "camera animation index out of range");
+        c.animation = rc.animation - 1;
         c.windowStart = windowStart;
         c.windowEnd = windowEnd;
         t->cameraBuffers[i]->allocate(static_cast<size_t>(rc.width) * rc.height * 3);
@@ -414,6 +420,22 @@ void buildScene(rt_tracer* t, const rt_scene* scene)
         t->gatherCache.emplace_back(new rt_tracer::GatherCache());
     }
 
+    // ---- keyframed poses: every track's key range is checked here, the kernels index without checks ----
+    require(scene->animation_count >= 0 && scene->keyframe_count >= 0, "bad animation counts");
+    std::vector<rt_animation> animations(scene->animations, scene->animations + scene->animation_count);
+    std::vector<rt_keyframe> keyframes(scene->keyframes, scene->keyframes + scene->keyframe_count);
+    for (const rt_animation& a : animations)
+    {
+        require(a.position_key_count >= 0 && a.first_position_key >= 0 &&
+                    a.first_position_key + a.position_key_count <= scene->keyframe_count,
+                "animation position keys out of range");
+        require(a.rotation_key_count >= 0 && a.first_rotation_key >= 0 &&
+                    a.first_rotation_key + a.rotation_key_count <= scene->keyframe_count,
+                "animation rotation keys out of range");
+    }
+    t->animations.upload(animations);
+    t->keyframes.upload(keyframes);
+
     t->volumes.upload(volumes);
     t->nodes.upload(nodes);
     t->triPos.upload(triPos);
@@ -455,6 +477,9 @@ void buildScene(rt_tracer* t, const rt_scene* scene)
     view.cameraTimeSamples = scene->settings.camera_time_samples;
     // probeSeed: base seed + 0x9E3779B9, truncated to 32 bits (reference src/Renderer.cpp:92-100)
     view.probeSeed = static_cast<uint32_t>(static_cast<long long>(view.seed) + 0x9E3779B9LL);
+    view.animations = t->animations.ptr;
+    view.keyframes = t->keyframes.ptr;
+    view.animationCount = static_cast<int32_t>(animations.size());
 }
 
 void resetState(rt_tracer* t)

@@ -136,6 +136,7 @@ struct Volume
 {
     int32_t type, material, nodeBase, nodeCount;
     int64_t triBase;  // first triangle of the mesh in the page-ordered arrays
+    int32_t animation, pad;  // index into SceneView::animations, or -1 for a static volume
     double pos[3];
     Quat rot, inv;    // rotation and Quaternion::inverse() of it (src/Quaternion.cpp:49-52)
     double param[18];
@@ -166,7 +167,8 @@ struct Camera
     double right[3], up[3], forward[3];
     double aspect, halfHeight, tanPixelHalfAngle;
     double orthographicHeight, apertureRadius, focusDistance;
-    int32_t width, height, bounceFilter, lightFilter, projection, pad;
+    int32_t width, height, bounceFilter, lightFilter, projection;
+    int32_t animation;  // index into SceneView::animations, or -1 for a static camera
     float windowStart, windowEnd;
     float* buffer;  // [h][w][3]
 };
@@ -216,6 +218,10 @@ struct SceneView
     float frameTime, shutterSpan;
     int32_t cameraTimeSamples;
     uint32_t probeSeed;
+    // keyframed poses (reference include/AnimationQuery.h:94-173); animationCount == 0: static scene
+    const rt_animation* animations;
+    const rt_keyframe* keyframes;
+    int32_t animationCount;
 };
 
 struct Ray
@@ -669,12 +675,129 @@ RT_DEV bool castMesh(const SceneView& s, const Volume& vol, const Ray& ray, cons
     return found;
 }
 
+// ------------------------------------------------------------------ keyframed poses
+// Property<T>::evaluate, reference include/Property.h:95-213: cubic Hermite through the
+// keyframes with Catmull-Rom tangents where none are given (:161-186), held outside the
+// keyed range.  `dims` is 1 for the angle track and 3 for the position track.
+RT_DEV double autoTangent(const rt_keyframe* keys, int64_t n, int64_t i, int d)
+{
+    if (n < 2) return 0.0;
+    int64_t a = i - 1, b = i + 1;
+    if (i == 0)
+    {
+        a = 0;
+        b = 1;
+    }
+    else if (i == n - 1)
+    {
+        a = n - 2;
+        b = n - 1;
+    }
+    const double span = keys[b].time - keys[a].time;
+    if (span <= 0.0) return 0.0;
+    return (keys[b].value[d] - keys[a].value[d]) * (1.0 / span);
+}
+
+RT_DEV void evaluateTrack(const rt_keyframe* keys, int64_t n, int dims, double t, double* out)
+{
+    int64_t held = -1;
+    int64_t idx = 1;
+    if (n == 1 || t <= keys[0].time)
+    {
+        held = 0;
+    }
+    else if (t >= keys[n - 1].time)
+    {
+        held = n - 1;
+    }
+    else
+    {
+        while (idx < n && keys[idx].time <= t)
+        {
+            ++idx;
+        }
+        if (keys[idx].time - keys[idx - 1].time <= 0.0)
+        {
+            held = idx - 1;
+        }
+    }
+    if (held >= 0)
+    {
+        for (int d = 0; d < dims; ++d) out[d] = keys[held].value[d];
+        return;
+    }
+    const rt_keyframe& k0 = keys[idx - 1];
+    const rt_keyframe& k1 = keys[idx];
+    const double dt = k1.time - k0.time;
+    const double u = (t - k0.time) / dt;
+    const double u2 = u * u;
+    const double u3 = u2 * u;
+    const double h00 = 2.0 * u3 - 3.0 * u2 + 1.0;
+    const double h10 = u3 - 2.0 * u2 + u;
+    const double h01 = -2.0 * u3 + 3.0 * u2;
+    const double h11 = u3 - u2;
+    for (int d = 0; d < dims; ++d)
+    {
+        const double m0 = k0.use_auto_tangent ? autoTangent(keys, n, idx - 1, d) : k0.out_tangent[d];
+        const double m1 = k1.use_auto_tangent ? autoTangent(keys, n, idx, d) : k1.in_tangent[d];
+        out[d] = k0.value[d] * h00 + m0 * (h10 * dt) + k1.value[d] * h01 + m1 * (h11 * dt);
+    }
+}
+
+struct Pose
+{
+    Vec position;
+    Quat rotation;
+};
+
+// KeyframedAnimationQuery::transformAt, reference include/AnimationQuery.h:130-158, with
+// Quaternion::fromAxisAngle (src/Quaternion.cpp:76-86) on the shared sin / cos.
+RT_DEV Pose poseAt(const SceneView& s, int32_t animation, float time)
+{
+    const rt_animation& a = s.animations[animation];
+    const double t = static_cast<double>(time);
+    Pose pose;
+    pose.position = mk(a.constant_position[0], a.constant_position[1], a.constant_position[2]);
+    if (a.position_key_count > 0)
+    {
+        double p[3];
+        evaluateTrack(s.keyframes + a.first_position_key, a.position_key_count, 3, t, p);
+        pose.position = mk(p[0], p[1], p[2]);
+    }
+    const Quat base{a.base_rotation[0], a.base_rotation[1], a.base_rotation[2], a.base_rotation[3]};
+    pose.rotation = base;
+    if (a.has_rotation)
+    {
+        double angle[1] = {0.0};  // an empty track is the constant 0
+        if (a.rotation_key_count > 0)
+        {
+            evaluateTrack(s.keyframes + a.first_rotation_key, a.rotation_key_count, 1, t, angle);
+        }
+        const double half = angle[0] / 2.0;
+        const double sa = rt_sin(half);
+        const double ca = rt_cos(half);
+        const Quat spin{a.rotation_axis[0] * sa, a.rotation_axis[1] * sa, a.rotation_axis[2] * sa, ca};
+        pose.rotation = qmul(spin, base);
+    }
+    return pose;
+}
+
+RT_DEV Quat quatInverse(const Quat& q)  // reference src/Quaternion.cpp:39-52
+{
+    const double m = q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w;
+    const double scale = 1.0 / m;
+    return Quat{-q.x * scale, -q.y * scale, -q.z * scale, q.w * scale};
+}
+
 // Nearest valid hit over all volumes: Volume::castRayAt for each volume in object
-// order (src/Volume.cpp:34-63), then the strict-minimum selection with the self-hit
+// order (src/Volume.cpp:34-81), then the strict-minimum selection with the self-hit
 // floor applied AFTER each volume's own closest hit was chosen
 // (src/Worker.cpp:556-567).  When `needSurface` is false only the distance is
-// produced (occlusion test, src/Worker.cpp:314-333).
-RT_DEV bool castScene(const SceneView& s, const Ray& ray, double selfHit, bool needSurface, Hit* out)
+// produced (occlusion test, src/Worker.cpp:314-333).  With Animated set, a keyframed
+// volume is posed at `time` (the photon's or the camera sample's) for the cast; without
+// it every volume keeps its scene-load transform and `time` is unused.
+template <bool Animated>
+RT_DEV bool castScene(const SceneView& s, const Ray& ray, float time, double selfHit, bool needSurface, Hit* out)
 {
     const TraversalStack stack = laneStack();
     double minDistance = kMaxDouble;
@@ -684,10 +807,17 @@ RT_DEV bool castScene(const SceneView& s, const Ray& ray, double selfHit, bool n
     for (int32_t v = 0; v < s.volumeCount; ++v)
     {
         const Volume& vol = s.volumes[v];
-        const Vec vpos = mk(vol.pos[0], vol.pos[1], vol.pos[2]);
+        Vec vpos = mk(vol.pos[0], vol.pos[1], vol.pos[2]);
+        Quat inv = vol.inv;
+        if (Animated && vol.animation >= 0)
+        {
+            const Pose pose = poseAt(s, vol.animation, time);
+            vpos = pose.position;
+            inv = quatInverse(pose.rotation);
+        }
         Ray local;
-        local.o = rotate(vol.inv, ray.o - vpos);
-        local.d = rotate(vol.inv, ray.d);
+        local.o = rotate(inv, ray.o - vpos);
+        local.d = rotate(inv, ray.d);
         Vec pos, nrm = mk(0, 0, 0);
         double dist;
         bool found = false;
@@ -740,8 +870,16 @@ RT_DEV bool castScene(const SceneView& s, const Ray& ray, double selfHit, bool n
     if (valid && needSurface)
     {
         const Volume& vol = s.volumes[bestVolume];
-        out->position = mk(vol.pos[0], vol.pos[1], vol.pos[2]) + rotate(vol.rot, bestPos);
-        out->normal = rotate(vol.rot, bestNrm);
+        Vec vpos = mk(vol.pos[0], vol.pos[1], vol.pos[2]);
+        Quat rot = vol.rot;
+        if (Animated && vol.animation >= 0)
+        {
+            const Pose pose = poseAt(s, vol.animation, time);  // the pose the winning cast used
+            vpos = pose.position;
+            rot = pose.rotation;
+        }
+        out->position = vpos + rotate(rot, bestPos);
+        out->normal = rotate(rot, bestNrm);
         out->material = vol.material;
         out->volume = bestVolume;
         out->triangle = bestTri;
@@ -1142,7 +1280,26 @@ RT_DEV Ray emitRay(const Light& l, Rng& rng)
 
 
 // ------------------------------------------------------------------ camera side
-// Camera::buildPrimaryRay, reference src/Camera.cpp:333-493 (static pose).
+// Camera::resolveEyeRotationAt, reference src/Camera.cpp:388-402: the camera with its eye
+// and axes at `time` (a static camera is returned as it is).
+RT_DEV Camera cameraAt(const SceneView& s, const Camera& cam, float time)
+{
+    Camera posed = cam;
+    if (cam.animation >= 0)
+    {
+        const Pose pose = poseAt(s, cam.animation, time);
+        const Vec right = rotate(pose.rotation, mk(1.0, 0.0, 0.0));
+        const Vec up = rotate(pose.rotation, mk(0.0, 1.0, 0.0));
+        const Vec forward = rotate(pose.rotation, mk(0.0, 0.0, 1.0));
+        posed.pos[0] = pose.position.x; posed.pos[1] = pose.position.y; posed.pos[2] = pose.position.z;
+        posed.right[0] = right.x; posed.right[1] = right.y; posed.right[2] = right.z;
+        posed.up[0] = up.x; posed.up[1] = up.y; posed.up[2] = up.z;
+        posed.forward[0] = forward.x; posed.forward[1] = forward.y; posed.forward[2] = forward.z;
+    }
+    return posed;
+}
+
+// Camera::buildPrimaryRay, reference src/Camera.cpp:404-493, for a camera already posed.
 RT_DEV Ray buildPrimaryRay(const Camera& cam, int32_t px, int32_t py, Rng* rng)
 {
     double offX = 0.5, offY = 0.5;
@@ -1192,9 +1349,9 @@ RT_DEV Ray buildPrimaryRay(const Camera& cam, int32_t px, int32_t py, Rng* rng)
 
 // firstHit + firstEmitterHit + intersectEmitterPatch, reference src/ProbeGather.cpp:57-127,
 // src/EmitterPatch.cpp:55-88.  material == -1 marks an emitter face.
-RT_DEV bool firstHit(const SceneView& s, const Ray& ray, Hit* closest)
+RT_DEV bool firstHit(const SceneView& s, const Ray& ray, float time, Hit* closest)
 {
-    bool found = castScene(s, ray, kEps, true, closest);
+    bool found = castScene<true>(s, ray, time, kEps, true, closest);
     double bestT = __builtin_inf();
     int32_t best = -1;
     for (int32_t i = 0; i < s.patchCount; ++i)
@@ -1248,7 +1405,7 @@ struct ExtendResult  // reference src/ProbeGather.cpp:138-147
 };
 
 // extendAndRecord, reference src/ProbeGather.cpp:154-229
-RT_DEV ExtendResult extendAndRecord(const SceneView& s, Rng& rng, Ray ray)
+RT_DEV ExtendResult extendAndRecord(const SceneView& s, Rng& rng, Ray ray, float time)
 {
     ExtendResult out;
     out.throughput = Color{1.0f, 1.0f, 1.0f};
@@ -1259,7 +1416,7 @@ RT_DEV ExtendResult extendAndRecord(const SceneView& s, Rng& rng, Ray ray)
     for (int depth = 0; depth < 8; ++depth)
     {
         Hit hit;
-        if (!firstHit(s, ray, &hit))
+        if (!firstHit(s, ray, time, &hit))
         {
             return out;
         }
@@ -1347,7 +1504,8 @@ template <class Emit>
 RT_DEV int collectPixel(const SceneView& s, int32_t cameraIndex, int32_t px, int32_t py, unsigned long long* stats,
                         Emit&& emit)
 {
-    const Camera& cam = s.cameras[cameraIndex];
+    const Camera& staticCam = s.cameras[cameraIndex];
+    Camera cam = staticCam;
     const bool motionActive = (s.shutterSpan > 0.0f) && (s.cameraTimeSamples > 1);
     const bool dofActive = (cam.projection == RT_PROJECTION_REALLENS) && (cam.apertureRadius > 0.0);
     const int motionSamples = motionActive ? s.cameraTimeSamples : 1;
@@ -1364,10 +1522,15 @@ RT_DEV int collectPixel(const SceneView& s, int32_t cameraIndex, int32_t px, int
     {
         const float sampleTime =
             motionActive ? s.frameTime + static_cast<float>(rng.value(static_cast<double>(s.shutterSpan))) : s.frameTime;
+        // Camera::generatePrimaryRayAt, reference src/Camera.cpp:375-402: an animated camera is posed at the sample's time
+        if (staticCam.animation >= 0)
+        {
+            cam = cameraAt(s, staticCam, sampleTime);
+        }
         const Ray ray = buildPrimaryRay(cam, px, py, dofActive ? &rng : nullptr);
         stats[0] += 1;
         Hit first;
-        if (!firstHit(s, ray, &first))
+        if (!firstHit(s, ray, sampleTime, &first))
         {
             stats[2] += 1;
             continue;
@@ -1400,7 +1563,7 @@ RT_DEV int collectPixel(const SceneView& s, int32_t cameraIndex, int32_t px, int
         const int extensionSamples = (stochasticDelta && !dofActive) ? 16 : 1;
         for (int ext = 0; ext < extensionSamples; ++ext)
         {
-            const ExtendResult chain = extendAndRecord(s, rng, ray);
+            const ExtendResult chain = extendAndRecord(s, rng, ray, sampleTime);
             if (chain.traversedDelta) stats[1] += 1;
             if (!chain.valid)
             {
@@ -1421,7 +1584,7 @@ RT_DEV int collectPixel(const SceneView& s, int32_t cameraIndex, int32_t px, int
                     adjRng.next = 0;
                     adjRng.seed = 0xC0FFEEu;
                     adjRng.begin(0xFFFFFFFFu, 0, 0);
-                    const ExtendResult adjChain = extendAndRecord(s, adjRng, adjRay);
+                    const ExtendResult adjChain = extendAndRecord(s, adjRng, adjRay, sampleTime);
                     if (adjChain.valid && adjChain.hit.material == chain.hit.material &&
                         dot(adjChain.hit.normal, chain.hit.normal) >= 0.5)
                     {

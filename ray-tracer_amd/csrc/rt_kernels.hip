@@ -261,6 +261,7 @@ struct LocalCounters
 // Worker::splatToCamera, reference src/Worker.cpp:221-427, with
 // Camera::coordForPointSubPixel (src/Camera.cpp:239-310), Utility::flooredSplatRadius
 // (src/Utility.cpp:43-50) and Buffer::addColor (src/Buffer.cpp:22-37).
+template <bool Animated>
 RT_DEV void splatToCamera(const TraceArgs& a, const Vec& incoming, const Color& photonColor, int bounces, int lightId,
                           float time, const Hit& hit, const Material& material, LocalCounters& lc)
 {
@@ -307,7 +308,7 @@ RT_DEV void splatToCamera(const TraceArgs& a, const Vec& incoming, const Color& 
         shadow.o = hit.position;
         shadow.d = toCameraDir;
         Hit occluder;
-        if (castScene(s, shadow, kSelfHitThreshold, false, &occluder) && occluder.distance < cameraDistance)
+        if (castScene<Animated>(s, shadow, time, kSelfHitThreshold, false, &occluder) && occluder.distance < cameraDistance)
         {
             continue;
         }
@@ -445,7 +446,7 @@ RT_DEV void sortChunk(const TraceArgs& a, unsigned long long chunkBase, uint32_t
 
 // Sink selects the deposit path and Record the per-photon path dump at compile time, so
 // that the probe-sink kernel carries neither the splat's shadow-ray cast nor the dump.
-template <int Sink, bool Record>
+template <int Sink, bool Record, bool Animated>
 __global__ __launch_bounds__(kTraceThreads) void traceKernel(const TraceArgs a)
 {
     const SceneView& s = a.scene;
@@ -579,7 +580,7 @@ __global__ __launch_bounds__(kTraceThreads) void traceKernel(const TraceArgs a)
             if (!done)
             {
                 casts += 1;
-                if (!castScene(s, ray, kSelfHitThreshold, true, &hit))
+                if (!castScene<Animated>(s, ray, time, kSelfHitThreshold, true, &hit))
                 {
                     done = true;  // escaped the scene
                 }
@@ -629,7 +630,7 @@ __global__ __launch_bounds__(kTraceThreads) void traceKernel(const TraceArgs a)
                         lc.densityDeposits += 1;
                         densityAdd(a.density, hit.position, color, lc.densityCells, lc.densityOverflow);
                     }
-                    splatToCamera(a, ray.d, color, bounces, lightId, time, hit, material, lc);
+                    splatToCamera<Animated>(a, ray.d, color, bounces, lightId, time, hit, material, lc);
                 }
 
                 // terminate: absolute decay floor or bounce cap (src/Worker.cpp:640-644,
@@ -716,7 +717,7 @@ __global__ __launch_bounds__(256) void castRaysKernel(const SceneView s, int64_t
     ray.o = mk(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]);
     ray.d = mk(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]);
     Hit hit;
-    const bool found = castScene(s, ray, selfHit, true, &hit);
+    const bool found = castScene<true>(s, ray, s.frameTime, selfHit, true, &hit);
     double* f = outF64 + 7 * i;
     int32_t* o = outI32 + 4 * i;
     if (found)
@@ -1439,28 +1440,30 @@ void launchTrace(const TraceArgs& args, int blocks, int threads, hipStream_t str
     const dim3 grid(blocks), block(kTraceThreads);
     const size_t lds = stackBytes(args.scene, kTraceThreads) + (kTraceThreads / 64) * kSortBytesPerWave;
     const bool record = args.records.recordPhotons > 0;
+    const bool animated = args.scene.animationCount > 0;
+    const int variant = (record ? 1 : 0) | (animated ? 2 : 0);
+#define RT_LAUNCH_TRACE(sink)                                                                                     \
+    switch (variant)                                                                                              \
+    {                                                                                                             \
+    case 0: hipLaunchKernelGGL((traceKernel<sink, false, false>), grid, block, lds, stream, args); break;         \
+    case 1: hipLaunchKernelGGL((traceKernel<sink, true, false>), grid, block, lds, stream, args); break;          \
+    case 2: hipLaunchKernelGGL((traceKernel<sink, false, true>), grid, block, lds, stream, args); break;          \
+    default: hipLaunchKernelGGL((traceKernel<sink, true, true>), grid, block, lds, stream, args); break;          \
+    }
     switch (args.sinkMode)
     {
-    case kSinkProbe:
-        if (record) hipLaunchKernelGGL((traceKernel<kSinkProbe, true>), grid, block, lds, stream, args);
-        else hipLaunchKernelGGL((traceKernel<kSinkProbe, false>), grid, block, lds, stream, args);
-        break;
-    case kSinkSplat:
-        if (record) hipLaunchKernelGGL((traceKernel<kSinkSplat, true>), grid, block, lds, stream, args);
-        else hipLaunchKernelGGL((traceKernel<kSinkSplat, false>), grid, block, lds, stream, args);
-        break;
-    default:
-        if (record) hipLaunchKernelGGL((traceKernel<kSinkNone, true>), grid, block, lds, stream, args);
-        else hipLaunchKernelGGL((traceKernel<kSinkNone, false>), grid, block, lds, stream, args);
-        break;
+    case kSinkProbe: RT_LAUNCH_TRACE(kSinkProbe); break;
+    case kSinkSplat: RT_LAUNCH_TRACE(kSinkSplat); break;
+    default: RT_LAUNCH_TRACE(kSinkNone); break;
     }
+#undef RT_LAUNCH_TRACE
 }
 
 int traceBlocksPerCu(const SceneView& scene)
 {
     int blocks = 0;
     // the grid is sized by the variant with the largest register footprint
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, traceKernel<kSinkSplat, true>, kTraceThreads,
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, traceKernel<kSinkSplat, true, true>, kTraceThreads,
                                                      stackBytes(scene, kTraceThreads) +
                                                          (kTraceThreads / 64) * kSortBytesPerWave) != hipSuccess ||
         blocks < 1)

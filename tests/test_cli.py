@@ -119,6 +119,42 @@ def test_cli_renders_frame_equal_to_oracle(rt, tmp_path, probe_gather):
 
 
 @pytest.mark.gpu
+def test_cli_renders_keyframed_frames(rt, tmp_path):
+    """$animation end to end: two frames of the keyframed scene (frame / frameRate is the frame
+    time, reference src/main.cpp:95-100), each equal to the oracle's frame at that time, and
+    different from one another."""
+    scene = json.load(open(os.path.join(REPO, "tests", "scenes", "animated.json")))
+    scene["$renderConfiguration"].update({"$photonsPerLight": 2500, "$renderPath": str(tmp_path / "out"),
+                                          "$renderName": "anim", "$frameRate": 10.0, "$frameOffset": 0.0})
+    frames = {}
+    for frame in (3, 7):
+        scene["$renderConfiguration"].update({"$startFrame": frame, "$endFrame": frame})
+        path = tmp_path / f"scene{frame}.json"
+        path.write_text(json.dumps(scene))
+        dump = tmp_path / f"dump{frame}"
+        r = run_cli(str(path), env=dict(os.environ, RT_DUMP_BUFFERS=str(dump)))
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        assert os.path.exists(tmp_path / "out" / f"anim.{frame}.png")
+
+        loaded = rt.Scene(str(path))
+        loaded.settings.frame_time = frame / 10.0
+        orc = O.Oracle(loaded)
+        setup = O.frame_setup(orc, O.RNG_COUNTER, O.MATH_PORTABLE)
+        keep = setup["keep_radius"]
+        emitters, _ = orc.deposit_emitters(setup["probes"], keep, keep, setup["emitter_spacing"])
+        ref = orc.trace(rng_mode=O.RNG_COUNTER, math_mode=O.MATH_PORTABLE, sink_mode=O.SINK_PROBE, threads=4,
+                        probes=setup["probes"], probe_cell_size=keep, keep_radius=keep,
+                        store_capacity=setup["store_capacity"], preload=emitters)
+        want, _ = orc.gather(0, ref["store"], setup["gather_cell"], setup["min_gather_radius"])
+        cam = loaded.desc.cameras[0]
+        got = np.fromfile(dump / "camera0.f32", dtype=np.float32).reshape(cam.height, cam.width, 3)
+        assert np.abs(want).max() > 0
+        np.testing.assert_allclose(got, want, rtol=2e-4, atol=1e-6 * float(np.abs(want).max()))
+        frames[frame] = got
+    assert image_check.rel_rmse(frames[3], frames[7]) > 1e-2
+
+
+@pytest.mark.gpu
 def test_cornell_box_image_equivalence(rt, tmp_path):
     """Image equivalence at equal photon count on a BASELINE configuration (CornellBox.json,
     reduced to 128 x 128 and 400 k photons so that the CPU oracle finishes in seconds): the

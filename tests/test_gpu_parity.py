@@ -109,6 +109,24 @@ def test_closest_hit_on_reference_rays(rt, golden, manifest, scene_opener):
         assert np.array_equal(got_i, o_i)
 
 
+def test_closest_hit_with_keyframed_volumes(rt, scene_opener):
+    """rt_cast_rays poses keyframed volumes at the frame time: same hits as the oracle at
+    several frame times, and the hits do move between them."""
+    seen = []
+    for frame_time in (0.0, 0.3, 0.85):
+        entry = {"scene": "tests/scenes/animated.json", "photons_per_light": 2000, "frame_time": frame_time}
+        scene, tracer, orc = _open(rt, scene_opener, entry)
+        pre = orc.trace(rng_mode=O.RNG_COUNTER, math_mode=O.MATH_PORTABLE, threads=8, record_photons=2000)
+        rays = pre["emitted"][:, :6].copy()
+        got_f, got_i = tracer.cast_rays(rays)
+        o_f, o_i = orc.cast_rays(rays)
+        assert (got_i[:, 0] == 1).sum() > 1000
+        assert_bits_equal(got_f, o_f, f"t={frame_time} hits vs oracle")
+        assert np.array_equal(got_i, o_i)
+        seen.append(got_f)
+    assert not np.array_equal(seen[0], seen[1]) and not np.array_equal(seen[1], seen[2])
+
+
 SCENES = {
     "furnace": {"scene": "tests/scenes/furnace.json", "photons_per_light": 4000},
     "mixed": {"scene": "tests/scenes/mixed.json", "photons_per_light": 1500},
@@ -118,6 +136,8 @@ SCENES = {
     "multicam": {"scene": "scenes/MultiCameraTest.json", "photons_per_light": 5000},
     "singlephoton": {"scene": "scenes/SinglePhotonVerify.json", "photons_per_light": 5000},
     "mirrordirect": {"scene": "scenes/MirrorDirectTest.json", "photons_per_light": 5000},
+    # keyframed plate, ball, knot and camera; photons are time-stamped across the shutter
+    "animated": {"scene": "tests/scenes/animated.json", "photons_per_light": 3000, "frame_time": 0.3},
 }
 
 
@@ -148,7 +168,7 @@ def _sorted_records(store):
     return store[order]
 
 
-@pytest.mark.parametrize("name", ["mixed", "cbgmd", "bombardment"])
+@pytest.mark.parametrize("name", ["mixed", "cbgmd", "bombardment", "animated"])
 def test_probe_sink_store_equals_oracle(rt, scene_opener, name):
     """Sink A: keep-test + BounceStore.  The store is a multiset (append order is a race in
     the reference too with > 1 worker): same records bit for bit after sorting; same counters."""
@@ -216,6 +236,7 @@ PROBE_SCENES = {
     "cbgmd": {"scene": "scenes/CornellBoxGlassMirrorDiffuse.json", "image": 128, "probe_sub_sample": 2, "seed": 3},
     "multicam": {"scene": "scenes/MultiCameraTest.json", "image": 96, "seed": 5},
     "shutter": {"scene": "tests/scenes/mixed.json", "shutter_time": 0.25, "camera_time_samples": 4},
+    "animated": {"scene": "tests/scenes/animated.json", "frame_time": 0.3},
 }
 
 
@@ -276,6 +297,7 @@ GATHER_SCENES = {
     "cbgmd": {"scene": "scenes/CornellBoxGlassMirrorDiffuse.json", "photons_per_light": 60000, "image": 96, "seed": 3},
     "bombardment": {"scene": "scenes/MirrorBombardment-200M.json", "photons_per_light": 400000, "image": 128,
                     "seed": 11},
+    "animated": {"scene": "tests/scenes/animated.json", "photons_per_light": 2500, "frame_time": 0.3},
 }
 
 
@@ -326,7 +348,7 @@ def test_gather_equals_oracle(rt, scene_opener, name):
         np.testing.assert_allclose(got, buffer, rtol=2e-4, atol=1e-6 * float(np.abs(buffer).max()))
 
 
-@pytest.mark.parametrize("name", ["mixed", "multicam", "cbgmd"])
+@pytest.mark.parametrize("name", ["mixed", "multicam", "cbgmd", "animated"])
 def test_splat_sink_equals_oracle(rt, scene_opener, name):
     """Sink B: direct camera splat (+ density grid).  Buffers are float-atomic sums, so they
     are compared to 1e-5 of the image's peak; counters are exact."""
