@@ -89,11 +89,26 @@ uint64_t rt_abi_struct_size(int32_t which);
 int32_t rt_device_count(void);
 
 /* Build a tracer for `scene` on GPU `device`: builds each mesh's tree with the
- * reference's median-split algorithm (reference src/Tree.cpp:289-362), flattens it,
- * and uploads volumes, materials, lights and cameras.  Stands in for the Worker
- * wiring block of Renderer::renderFrame (reference src/Renderer.cpp:421-459). */
+ * reference's median-split algorithm (reference src/Tree.cpp:289-362) to learn every
+ * triangle's visiting rank and node box, then a surface-area tree over the same
+ * triangles that returns the same closest hit (see rt_check_tree), flattens it, and
+ * uploads volumes, materials, lights and cameras.  Stands in for the Worker wiring
+ * block of Renderer::renderFrame (reference src/Renderer.cpp:421-459).
+ * Environment: RT_AMD_TREE=reference walks the reference's own tree instead (for
+ * comparison runs); RT_AMD_LEAF=<1..16> triangles per leaf (default 4). */
 int32_t rt_create(const rt_scene* scene, int32_t device, rt_tracer** out);
 void rt_destroy(rt_tracer* tracer);
+
+/* Host only (no GPU needed): builds both trees of one mesh (tri_pos: 9 doubles per triangle,
+ * `count` triangles; Tree's constructor, reference src/Tree.cpp:289-362, and the surface-area
+ * tree with `leaf_size` triangles per leaf and boxes grown by `pad`) and verifies what the
+ * device walk relies on: both hold every triangle exactly once; child ranges and skip links
+ * are consistent; every surface-area box contains its triangles' vertices with `pad` to
+ * spare and its children's boxes; ranks are a permutation of the reference's visiting order;
+ * every triangle's reference box is the box of the reference node whose page holds it and
+ * contains the triangle.  stats = {reference nodes, reference depth, surface-area nodes,
+ * surface-area depth, leaves, largest leaf}.  RT_OK, or RT_ERR_* with rt_last_error(). */
+int32_t rt_check_tree(const double* tri_pos, int64_t count, int32_t leaf_size, double pad, int64_t stats[6]);
 
 /* Launch on this HIP stream (a hipStream_t passed as void*; NULL = null stream). */
 int32_t rt_set_stream(rt_tracer* tracer, void* hip_stream);

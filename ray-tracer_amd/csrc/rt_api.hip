@@ -9,6 +9,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <map>
@@ -127,7 +129,7 @@ struct rt_tracer
 
     DeviceArray<rtd::Volume> volumes;
     DeviceArray<rtd::Node> nodes;
-    DeviceArray<double> triPos, triNrm;
+    DeviceArray<double> triRec, triNrm;
     DeviceArray<int32_t> triId;
     DeviceArray<rtd::Material> materials;
     DeviceArray<rtd::Light> lights;
@@ -203,8 +205,55 @@ void buildScene(rt_tracer* t, const rt_scene* scene)
 
     // ---- meshes: reference tree, flattened; triangles re-ordered by page ----
     std::vector<rtd::Node> nodes;
-    std::vector<double> triPos, triNrm;
+    std::vector<double> triRec, triNrm;
     std::vector<int32_t> triId;
+    // RT_AMD_TREE=reference keeps the reference's own median-split trees (for comparison runs);
+    // the default is the surface-area tree over the same triangles, which returns the same hits.
+    const char* treeChoice = std::getenv("RT_AMD_TREE");
+    const bool referenceTree = treeChoice != nullptr && std::strcmp(treeChoice, "reference") == 0;
+    require(treeChoice == nullptr || referenceTree || std::strcmp(treeChoice, "surface-area") == 0,
+            "RT_AMD_TREE must be 'reference' or 'surface-area'");
+    int leafSize = 4;
+    if (const char* leaf = std::getenv("RT_AMD_LEAF"))
+    {
+        leafSize = std::atoi(leaf);
+        require(leafSize >= 1 && leafSize <= 16, "RT_AMD_LEAF must be between 1 and 16");
+    }
+    // coordinate scale of the scene: a bound on the coordinates a ray origin or a hit can have,
+    // in world space and (volume positions included) in any volume's object space
+    double sceneScale = 0.0, reach = 0.0;
+    for (int64_t i = 0; i < scene->volume_count; ++i)
+    {
+        for (int k = 0; k < 3; ++k) sceneScale = std::max(sceneScale, std::fabs(scene->volumes[i].position[k]));
+        if (scene->volumes[i].type != RT_VOLUME_MESH && scene->volumes[i].type != RT_VOLUME_PLANE)
+        {
+            for (double p : scene->volumes[i].param) reach = std::max(reach, std::fabs(p));
+        }
+    }
+    for (int64_t i = 0; i < scene->keyframe_count; ++i)
+    {
+        for (int k = 0; k < 3; ++k) sceneScale = std::max(sceneScale, std::fabs(scene->keyframes[i].value[k]));
+    }
+    for (int64_t i = 0; i < scene->animation_count; ++i)
+    {
+        for (int k = 0; k < 3; ++k)
+        {
+            sceneScale = std::max(sceneScale, std::fabs(scene->animations[i].constant_position[k]));
+        }
+    }
+    for (int64_t i = 0; i < scene->light_count; ++i)
+    {
+        for (int k = 0; k < 3; ++k) sceneScale = std::max(sceneScale, std::fabs(scene->lights[i].position[k]));
+    }
+    for (int64_t i = 0; i < scene->camera_count; ++i)
+    {
+        for (int k = 0; k < 3; ++k) sceneScale = std::max(sceneScale, std::fabs(scene->cameras[i].position[k]));
+    }
+    for (int64_t i = 0; i < 9 * scene->triangle_count; ++i)
+    {
+        reach = std::max(reach, std::fabs(scene->tri_pos[i]));
+    }
+    sceneScale = 2.0 * (sceneScale + reach);
     struct MeshSpan
     {
         int32_t nodeBase, nodeCount;
@@ -222,7 +271,25 @@ void buildScene(rt_tracer* t, const rt_scene* scene)
         const double* pos = scene->tri_pos + 9 * mesh.first_triangle;
         const double* nrm = scene->tri_nrm + 9 * mesh.first_triangle;
         rtbvh::FlatMesh flat = rtbvh::build(pos, mesh.triangle_count);
+        if (!referenceTree)
+        {
+            // padding: far above the rounding of a slab test on coordinates of this size, far
+            // below anything that would cost traversal steps
+            double extent = 0.0;
+            for (int64_t i = 0; i < 9 * mesh.triangle_count; ++i)
+            {
+                extent = std::max(extent, std::fabs(pos[i]));
+            }
+            const double pad = 1e-7 * extent + 1e-10 * sceneScale;
+            flat = rtbvh::buildSurfaceArea(pos, mesh.triangle_count, flat, pad, leafSize);
+        }
         maxDepth = std::max(maxDepth, flat.depth);
+        if (std::getenv("RT_AMD_VERBOSE"))
+        {
+            std::fprintf(stderr, "[rt_amd] mesh %lld: %lld triangles, %zu nodes, depth %d (%s tree)\n",
+                         static_cast<long long>(m), static_cast<long long>(mesh.triangle_count), flat.nodes.size(),
+                         flat.depth, referenceTree ? "reference" : "surface-area");
+        }
         MeshSpan span;
         span.nodeBase = static_cast<int32_t>(nodes.size());
         span.nodeCount = static_cast<int32_t>(flat.nodes.size());
@@ -238,9 +305,40 @@ void buildScene(rt_tracer* t, const rt_scene* scene)
             n.right = fn.right;
             nodes.push_back(n);
         }
-        for (int32_t original : flat.order)
+        for (size_t slot = 0; slot < flat.order.size(); ++slot)
         {
-            triPos.insert(triPos.end(), pos + 9 * original, pos + 9 * original + 9);
+            const int32_t original = flat.order[slot];
+            const double* p = pos + 9 * original;
+            // One 128-byte record per triangle: vertices, the box of its reference node, and one
+            // word holding its reference rank (low half) and, as a float, the smallest barycentric
+            // weight from which a hit is certain to pass the reference's slab test on that box
+            // without running it (high half).  A hit point with weights >= w lies at least
+            // w x (the triangle's extent along k) inside the box along every axis k the triangle
+            // extends in, and that has to exceed the few-ulp relative rounding of the slab
+            // parameters, i.e. ~1e-15 x the scene's coordinate scale; the constant below leaves four
+            // orders of magnitude.  With the reference's own tree every reached triangle is
+            // admitted by construction (-1 admits any weight).
+            float certain = -1.0f;
+            if (!referenceTree)
+            {
+                double narrowest = std::numeric_limits<double>::infinity();
+                for (int k = 0; k < 3; ++k)
+                {
+                    const double extent = std::max({p[k], p[3 + k], p[6 + k]}) - std::min({p[k], p[3 + k], p[6 + k]});
+                    if (extent > 0.0) narrowest = std::min(narrowest, extent);
+                }
+                const double weight = 1e-10 * sceneScale / narrowest;  // 0 for a triangle without extent: it is never hit
+                certain = static_cast<float>(std::min(weight, 2.0));
+                certain = std::nextafter(certain, 3.0f);  // the conversion may have rounded down
+            }
+            uint32_t certainBits;
+            std::memcpy(&certainBits, &certain, sizeof(certainBits));
+            const uint64_t word = (static_cast<uint64_t>(certainBits) << 32) | static_cast<uint32_t>(flat.rank[slot]);
+            double wordAsDouble;
+            std::memcpy(&wordAsDouble, &word, sizeof(word));
+            triRec.insert(triRec.end(), p, p + 9);
+            triRec.insert(triRec.end(), flat.referenceBox.begin() + 6 * slot, flat.referenceBox.begin() + 6 * slot + 6);
+            triRec.push_back(wordAsDouble);
             triNrm.insert(triNrm.end(), nrm + 9 * original, nrm + 9 * original + 9);
             triId.push_back(original);
         }
@@ -438,7 +536,7 @@ void buildScene(rt_tracer* t, const rt_scene* scene)
 
     t->volumes.upload(volumes);
     t->nodes.upload(nodes);
-    t->triPos.upload(triPos);
+    t->triRec.upload(triRec);
     t->triNrm.upload(triNrm);
     t->triId.upload(triId);
     t->materials.upload(materials);
@@ -450,7 +548,7 @@ void buildScene(rt_tracer* t, const rt_scene* scene)
     rtd::SceneView& view = t->view;
     view.volumes = t->volumes.ptr;
     view.nodes = t->nodes.ptr;
-    view.triPos = t->triPos.ptr;
+    view.triRec = t->triRec.ptr;
     view.triNrm = t->triNrm.ptr;
     view.triId = t->triId.ptr;
     view.materials = t->materials.ptr;
@@ -747,6 +845,116 @@ int32_t rt_device_count(void)
         return 0;
     }
     return n;
+}
+
+int32_t rt_check_tree(const double* tri_pos, int64_t count, int32_t leaf_size, double pad, int64_t stats[6])
+{
+    return guarded([&]() {
+        require(count >= 0 && (tri_pos != nullptr || count == 0) && stats != nullptr, "null argument");
+        require(leaf_size >= 1 && leaf_size <= 16 && pad >= 0.0, "bad leaf size or padding");
+        const rtbvh::FlatMesh reference = rtbvh::build(tri_pos, count);
+        const rtbvh::FlatMesh tree = rtbvh::buildSurfaceArea(tri_pos, count, reference, pad, leaf_size);
+        const size_t n = static_cast<size_t>(count);
+        auto triangleInside = [&](int32_t original, const double* lo, const double* hi, double margin) {
+            for (int v = 0; v < 3; ++v)
+            {
+                for (int k = 0; k < 3; ++k)
+                {
+                    const double c = tri_pos[9 * static_cast<size_t>(original) + 3 * v + k];
+                    if (!(c - margin >= lo[k] && c + margin <= hi[k])) return false;
+                }
+            }
+            return true;
+        };
+        // both trees: every triangle once; links consistent
+        int64_t leaves = 0, largestLeaf = 0;
+        for (const rtbvh::FlatMesh* mesh : {&reference, &tree})
+        {
+            require(mesh->order.size() == n && mesh->rank.size() == n && mesh->referenceBox.size() == 6 * n,
+                    "tree does not hold one slot per triangle");
+            std::vector<char> seen(n, 0);
+            for (int32_t original : mesh->order)
+            {
+                require(original >= 0 && static_cast<size_t>(original) < n && !seen[static_cast<size_t>(original)],
+                        "triangle missing or repeated");
+                seen[static_cast<size_t>(original)] = 1;
+            }
+            const int32_t nodeCount = static_cast<int32_t>(mesh->nodes.size());
+            require(nodeCount >= 1, "tree has no root");
+            int64_t slots = 0;
+            for (int32_t i = 0; i < nodeCount; ++i)
+            {
+                const rtbvh::FlatNode& node = mesh->nodes[static_cast<size_t>(i)];
+                require(node.skip > i && node.skip <= nodeCount, "skip link out of range");
+                require(node.triCount >= 0 && node.triStart == slots, "pages are not contiguous in node order");
+                slots += node.triCount;
+                const bool hasLeft = node.skip > i + 1 && node.right != i + 1;
+                require(node.right == -1 || (node.right > i && node.right < node.skip), "right child out of range");
+                if (hasLeft)
+                {
+                    const int32_t afterLeft = mesh->nodes[static_cast<size_t>(i + 1)].skip;
+                    require(node.right == -1 ? afterLeft == node.skip : afterLeft == node.right,
+                            "left subtree does not end where the right one starts");
+                }
+                if (node.right >= 0)
+                {
+                    require(mesh->nodes[static_cast<size_t>(node.right)].skip == node.skip,
+                            "right subtree does not end with its parent");
+                }
+            }
+            require(slots == count, "pages do not add up to the triangle count");
+        }
+        // surface-area tree: boxes contain their triangles with the padding to spare, and their children
+        std::vector<int32_t> parent(tree.nodes.size(), -1);
+        for (size_t i = 0; i < tree.nodes.size(); ++i)
+        {
+            const rtbvh::FlatNode& node = tree.nodes[i];
+            const bool leaf = node.skip == static_cast<int32_t>(i) + 1;
+            if (leaf)
+            {
+                leaves += 1;
+                largestLeaf = std::max<int64_t>(largestLeaf, node.triCount);
+                require(count == 0 || node.triCount >= 1, "empty leaf");
+            }
+            else
+            {
+                require(node.triCount == 0 && node.right > static_cast<int32_t>(i) + 1, "inner node holds triangles or lacks a child");
+                parent[i + 1] = static_cast<int32_t>(i);
+                parent[static_cast<size_t>(node.right)] = static_cast<int32_t>(i);
+            }
+            for (int32_t slot = node.triStart; slot < node.triStart + node.triCount; ++slot)
+            {
+                // checked against the node and, through the chain of parents, every ancestor
+                for (int32_t a = static_cast<int32_t>(i); a >= 0; a = parent[static_cast<size_t>(a)])
+                {
+                    const rtbvh::FlatNode& box = tree.nodes[static_cast<size_t>(a)];
+                    require(triangleInside(tree.order[static_cast<size_t>(slot)], box.bmin, box.bmax, 0.999 * pad),
+                            "padded box does not contain its triangle");
+                }
+            }
+        }
+        require(largestLeaf <= leaf_size, "leaf larger than asked for");
+        // ranks and reference boxes
+        std::vector<char> rankSeen(n, 0);
+        for (size_t slot = 0; slot < n; ++slot)
+        {
+            const int32_t rank = tree.rank[slot];
+            require(rank >= 0 && static_cast<size_t>(rank) < n && !rankSeen[static_cast<size_t>(rank)], "ranks are not a permutation");
+            rankSeen[static_cast<size_t>(rank)] = 1;
+            require(reference.order[static_cast<size_t>(rank)] == tree.order[slot], "rank points at another triangle");
+            require(std::equal(tree.referenceBox.begin() + 6 * slot, tree.referenceBox.begin() + 6 * slot + 6,
+                               reference.referenceBox.begin() + 6 * rank),
+                    "reference box differs from the reference tree's");
+            require(triangleInside(tree.order[slot], &tree.referenceBox[6 * slot], &tree.referenceBox[6 * slot + 3], 0.0),
+                    "reference box does not contain its triangle");
+        }
+        stats[0] = static_cast<int64_t>(reference.nodes.size());
+        stats[1] = reference.depth;
+        stats[2] = static_cast<int64_t>(tree.nodes.size());
+        stats[3] = tree.depth;
+        stats[4] = leaves;
+        stats[5] = largestLeaf;
+    });
 }
 
 int32_t rt_create(const rt_scene* scene, int32_t device, rt_tracer** out)

@@ -28,11 +28,27 @@ struct FlatNode
 struct FlatMesh
 {
     std::vector<FlatNode> nodes;
-    std::vector<int32_t> order;  // page-ordered slot -> triangle index in load order
+    std::vector<int32_t> order;  // slot -> triangle index in load order
     int depth = 0;
+    // Per slot: the triangle's rank in the reference's visiting order and the box (min xyz,
+    // max xyz) of the reference node whose page holds it.
+    std::vector<int32_t> rank;
+    std::vector<double> referenceBox;
 };
 
-// tri_pos: 9 doubles per triangle (a, b, c), `count` triangles in load order.
+// The reference's tree.  tri_pos: 9 doubles per triangle (a, b, c), `count` triangles in load order.
 FlatMesh build(const double* tri_pos, int64_t count);
+
+// A tree of better quality over the same triangles: binned surface-area splits, up to
+// `leaf_size` triangles per leaf, none in inner nodes, every box grown by `pad` on all sides.
+// The closest hit the reference reports is "of the triangles whose OWN reference node's box
+// passes the slab test and whose watertight test hits, the nearest, earliest-visited first":
+// a reference node's box lies inside every ancestor's (each is the exact min / max over a
+// superset of triangles) and the slab test's rounded operations are monotone in the box
+// planes, so passing the own node's box implies passing every ancestor's.  The tree
+// therefore only has to REACH every such triangle (hence the padding: a ray that hits a
+// triangle meets the padded box that holds it whatever the rounding); `rank` and
+// `referenceBox` let the walk apply the reference's admission test and tie-break per hit.
+FlatMesh buildSurfaceArea(const double* tri_pos, int64_t count, const FlatMesh& reference, double pad, int leaf_size);
 
 }  // namespace rtbvh

@@ -197,9 +197,13 @@ struct SceneView
 {
     const Volume* volumes;
     const Node* nodes;
-    const double* triPos;  // [9 * T] page order
+    // [16 * T], one 128-byte record per triangle slot: vertices a b c (9), the box of the
+    // reference node whose page holds the triangle (6), and a word with the triangle's rank in the
+    // reference's visiting order (low half) and the barycentric weight from which a hit is
+    // certainly admitted by that box (float, high half)
+    const double* triRec;
     const double* triNrm;  // [9 * T] page order
-    const int32_t* triId;  // page order -> index within the mesh (load order)
+    const int32_t* triId;  // slot -> index within the mesh (load order)
     const Material* materials;
     const Light* lights;
     Camera* cameras;
@@ -293,16 +297,19 @@ struct RayPrep
     int kx, ky, kz;      // watertight axis permutation, src/Ray.cpp:100-139
     double sx, sy, sz;   // shear constants, :141-147
     double okx, oky, okz;  // ray origin in permuted order
+    bool parallel;         // some axis is treated as parallel by the slab test
 };
 
 RT_DEV RayPrep prepareRay(const Ray& ray)
 {
     RayPrep p;
+    p.parallel = false;
 #pragma unroll
     for (int i = 0; i < 3; ++i)
     {
         const double d = axisOf(ray.d, i);
         const bool parallel = dabs(d) < kEps;
+        p.parallel = p.parallel || parallel;
         const double ood = 1.0 / d;
         p.ood[i] = parallel ? __builtin_inf() : ood;
         const bool reversed = !parallel && ood < 0.0;
@@ -543,9 +550,11 @@ RT_DEV TraversalStack laneStack()
 // (src/Tree.cpp:133-152,207-237).  The reference visits every node whose box (and
 // whose ancestors' boxes) the ray meets, in page / left / right order, and keeps a
 // candidate only when it is strictly closer, so of equally distant hits the one
-// visited first wins.  The triangles are stored in that visiting order, so the same
-// winner is "smallest distance, then smallest slot" — which no longer depends on the
-// order of the walk.  That frees the walk to go near child first and to leave out any
+// visited first wins.  Every triangle carries its rank in that visiting order (its slot
+// itself when the tree is the reference's own), so the same winner is "smallest distance,
+// then smallest rank" — which no longer depends on the order of the walk, nor on the
+// shape of the tree as long as the walk reaches every triangle the reference would test
+// and admits only those (see SceneView::triRec).  That frees the walk to go near child first and to leave out any
 // subtree the ray enters beyond the best distance so far (or beyond `bound`, the
 // distance another volume has already achieved): such a subtree cannot hold a hit
 // that wins.  The comparison carries a margin far above the rounding of the box
@@ -563,7 +572,7 @@ RT_DEV bool castMesh(const SceneView& s, const Volume& vol, const Ray& ray, cons
     }
     RT_DIAG_TRIP(0);  // mesh casts
     const Node* nodes = s.nodes + vol.nodeBase;
-    const double* triPos = s.triPos + 9 * vol.triBase;
+    const double* triRec = s.triRec + 16 * vol.triBase;
     const double dlen = magnitude(ray.d);
     const Node& root = nodes[0];
     double extent = 0.0;
@@ -575,7 +584,7 @@ RT_DEV bool castMesh(const SceneView& s, const Volume& vol, const Ray& ray, cons
     const double slack = 1e-11 * (extent + dabs(ray.o.x) + dabs(ray.o.y) + dabs(ray.o.z));
     bool found = false;
     double best = kMaxDouble;
-    int32_t bestSlot = 0x7fffffff;
+    int32_t bestSlot = 0x7fffffff, bestRank = 0x7fffffff;
     double cutoff = bound * (1.0 + 1e-9) + slack;  // kMaxDouble -> +inf: nothing is pruned
 
     double rootEntry;
@@ -653,13 +662,32 @@ RT_DEV bool castMesh(const SceneView& s, const Volume& vol, const Ray& ray, cons
             RT_DIAG_TRIP(6);  // triangle tests
             double b3[3], d;
             Vec pos;
-            if (rayIntersectsTriangle(ray, prep, triPos + 9 * t, b3, &pos, &d))
+            const double* rec = triRec + 16 * t;
+            // rank and admission weight travel with the vertices: same 128-byte line, same wait
+            const unsigned long long word = reinterpret_cast<const unsigned long long*>(rec)[15];
+            if (rayIntersectsTriangle(ray, prep, rec, b3, &pos, &d))
             {
-                if (!found || d < best || (d == best && t < bestSlot))
+                const int32_t rank = static_cast<int32_t>(static_cast<uint32_t>(word));
+                bool wins = !found || d < best || (d == best && rank < bestRank);
+                if (wins)
+                {
+                    // The reference tests a triangle only when the ray meets its own node's box
+                    // (and with it every ancestor's).  Away from the triangle's edges that is
+                    // certain; otherwise, or when the ray runs parallel to an axis, ask the box.
+                    const double certain = static_cast<double>(__uint_as_float(static_cast<uint32_t>(word >> 32)));
+                    const double least = dmin(b3[0], dmin(b3[1], b3[2]));
+                    if (prep.parallel || !(least >= certain))
+                    {
+                        double ignored;
+                        wins = slabTest(ray, prep, rec + 9, &ignored);
+                    }
+                }
+                if (wins)
                 {
                     found = true;
                     best = d;
                     bestSlot = t;
+                    bestRank = rank;
                     bary[0] = b3[0];
                     bary[1] = b3[1];
                     bary[2] = b3[2];

@@ -35,6 +35,7 @@ _SIGNATURES = {
     "rt_last_error": (C.c_char_p, []),
     "rt_abi_struct_size": (C.c_uint64, [C.c_int32]),
     "rt_device_count": (C.c_int32, []),
+    "rt_check_tree": (C.c_int32, [C.POINTER(C.c_double), C.c_int64, C.c_int32, C.c_double, C.POINTER(C.c_int64)]),
     "rt_create": (C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]),
     "rt_destroy": (None, [C.c_void_p]),
     "rt_set_stream": (C.c_int32, [C.c_void_p, C.c_void_p]),

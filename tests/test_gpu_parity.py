@@ -163,6 +163,32 @@ def test_photon_paths_bit_exact_vs_oracle(rt, scene_opener, name):
     assert np.allclose(counters["deposited_power"], ref["deposited_power"], rtol=1e-9)
 
 
+@pytest.mark.parametrize("name,photons", [("bombardment", 3_000_000), ("knot", 400_000), ("cbgmd", 400_000),
+                                          ("animated", 200_000)])
+def test_surface_area_tree_returns_reference_tree_hits(rt, scene_opener, name, photons, monkeypatch):
+    """The default tree (surface-area splits, padded boxes, several triangles per leaf) must report
+    exactly what a walk of the reference's own median-split tree reports: same counters over
+    millions of casts, and the same path bits and triangle ids for the recorded photons."""
+    entry = dict(SCENES[name], photons_per_light=photons)
+    results = {}
+    for tree in ("reference", "surface-area"):
+        monkeypatch.setenv("RT_AMD_TREE", tree)
+        scene = scene_opener(entry)
+        tracer = rt.Tracer(scene)
+        tracer.reset()
+        tracer.trace(sink_mode=0, record_photons=50_000)
+        results[tree] = (tracer.counters(), tracer.records())
+    (c0, r0), (c1, r1) = results["reference"], results["surface-area"]
+    for k in ("photons", "casts", "bounces", "deposits"):
+        assert c0[k] == c1[k], k
+    assert c0["bounces"] > photons // 2
+    assert_bits_equal(r0["bounce_f64"], r1["bounce_f64"], "hits")
+    assert np.array_equal(r0["bounce_i32"], r1["bounce_i32"]), "ids"
+    assert np.array_equal(r0["casts_valid"], r1["casts_valid"])
+    assert_bits_equal(r0["bounce_power"], r1["bounce_power"], "power")
+    assert np.allclose(c0["deposited_power"], c1["deposited_power"], rtol=1e-12)
+
+
 def _sorted_records(store):
     order = np.lexsort(store.view(np.uint32).T[::-1])
     return store[order]

@@ -1,0 +1,94 @@
+"""Host-side checks of the two mesh trees (no GPU): the reference's median-split tree that
+fixes every triangle's visiting rank and node box, and the surface-area tree the device walks.
+rt_check_tree verifies inside the library the properties the walk relies on; here it is driven
+over ordinary and degenerate meshes."""
+import ctypes as C
+import importlib
+
+import numpy as np
+import pytest
+
+tracer = importlib.import_module("ray-tracer_amd.tracer")
+
+
+def check(tri_pos, leaf=4, pad=1e-7):
+    tri_pos = np.ascontiguousarray(tri_pos, dtype=np.float64).reshape(-1, 9)
+    stats = (C.c_int64 * 6)()
+    lib = tracer.tracer_lib()
+    code = lib.rt_check_tree(tri_pos.ctypes.data_as(C.POINTER(C.c_double)), tri_pos.shape[0], leaf, pad, stats)
+    assert code == 0, lib.rt_last_error().decode()
+    return dict(zip(("ref_nodes", "ref_depth", "nodes", "depth", "leaves", "largest_leaf"), list(stats)))
+
+
+def sphere(n_lat, n_lon, radius=50.0):
+    lat = np.linspace(0.0, np.pi, n_lat + 1)
+    lon = np.linspace(0.0, 2 * np.pi, n_lon + 1)
+    p = lambda a, b: radius * np.array([np.sin(a) * np.cos(b), np.cos(a), np.sin(a) * np.sin(b)])
+    tris = []
+    for i in range(n_lat):
+        for j in range(n_lon):
+            a, b, c, d = p(lat[i], lon[j]), p(lat[i + 1], lon[j]), p(lat[i + 1], lon[j + 1]), p(lat[i], lon[j + 1])
+            tris += [np.concatenate([a, b, c]), np.concatenate([a, c, d])]
+    return np.array(tris)
+
+
+@pytest.mark.parametrize("leaf", [1, 2, 4, 8])
+def test_sphere_mesh(leaf):
+    mesh = sphere(20, 24)
+    s = check(mesh, leaf)
+    n = mesh.shape[0]
+    assert s["ref_nodes"] <= n and s["ref_depth"] >= int(np.log2(n))
+    assert s["largest_leaf"] <= leaf and s["leaves"] >= n // leaf
+    assert s["nodes"] == 2 * s["leaves"] - 1
+    # the depth budget: balanced depth + 6 while that stays within 15 levels, else + 2
+    balanced = 1 + int(np.ceil(np.log2(max(1, n / leaf))))
+    assert s["depth"] <= max(balanced + 2, min(balanced + 6, 15))
+
+
+def test_random_soup_and_large_mesh():
+    rng = np.random.default_rng(3)
+    soup = rng.uniform(-100, 100, size=(5000, 1, 3)) + rng.normal(0, 3, size=(5000, 3, 3))
+    s = check(soup.reshape(-1, 9))
+    assert s["largest_leaf"] <= 4 and s["depth"] <= 15
+    big = rng.uniform(-1, 1, size=(200_000, 1, 3)) + rng.normal(0, 0.01, size=(200_000, 3, 3))
+    s = check(big.reshape(-1, 9))
+    assert s["largest_leaf"] <= 4 and s["depth"] <= 1 + 16 + 2
+
+
+@pytest.mark.parametrize("count", [0, 1, 2, 3, 5])
+def test_tiny_meshes(count):
+    rng = np.random.default_rng(count)
+    s = check(rng.uniform(-1, 1, size=(count, 9)))
+    assert s["leaves"] >= 1 and s["nodes"] >= 1
+
+
+def test_degenerate_meshes():
+    one = np.array([[0, 0, 0, 1, 0, 0, 0, 1, 0]], dtype=np.float64)
+    # every centroid equal: no split plane separates them, counts are halved instead
+    s = check(np.repeat(one, 37, axis=0))
+    assert s["largest_leaf"] <= 4 and s["leaves"] >= 10
+    # the reference keeps equal-centroid triangles in ONE node's page
+    assert s["ref_nodes"] == 1
+    # flat mesh (a wall): zero extent along one axis
+    grid = []
+    for i in range(12):
+        for j in range(12):
+            grid.append([150, i, j, 150, i + 1, j, 150, i, j + 1])
+            grid.append([150, i + 1, j, 150, i + 1, j + 1, 150, i, j + 1])
+    check(np.array(grid, dtype=np.float64), pad=0.0)
+    check(np.array(grid, dtype=np.float64))
+    # points and needles
+    check(np.zeros((9, 9)))
+    needles = np.zeros((50, 9))
+    needles[:, 3] = np.arange(50)
+    needles[:, 6] = np.arange(50) * 2.0
+    check(needles)
+
+
+def test_bad_arguments_are_reported():
+    lib = tracer.tracer_lib()
+    stats = (C.c_int64 * 6)()
+    one = np.zeros((1, 9))
+    assert lib.rt_check_tree(one.ctypes.data_as(C.POINTER(C.c_double)), 1, 0, 0.0, stats) != 0
+    assert b"leaf" in lib.rt_last_error()
+    assert lib.rt_check_tree(None, 3, 4, 0.0, stats) != 0
