@@ -94,8 +94,8 @@ int32_t rt_device_count(void);
  * triangles that returns the same closest hit (see rt_check_tree), flattens it, and
  * uploads volumes, materials, lights and cameras.  Stands in for the Worker wiring
  * block of Renderer::renderFrame (reference src/Renderer.cpp:421-459).
- * Environment: RT_AMD_TREE=reference walks the reference's own tree instead (for
- * comparison runs); RT_AMD_LEAF=<1..16> triangles per leaf (default 4). */
+ * Environment: RT_AMD_LEAF=<1..16> triangles per leaf (default 4); RT_AMD_VERBOSE=1
+ * prints each mesh's node count and depth. */
 int32_t rt_create(const rt_scene* scene, int32_t device, rt_tracer** out);
 void rt_destroy(rt_tracer* tracer);
 
@@ -106,7 +106,8 @@ void rt_destroy(rt_tracer* tracer);
  * are consistent; every surface-area box contains its triangles' vertices with `pad` to
  * spare and its children's boxes; ranks are a permutation of the reference's visiting order;
  * every triangle's reference box is the box of the reference node whose page holds it and
- * contains the triangle.  stats = {reference nodes, reference depth, surface-area nodes,
+ * contains the triangle; the two-box nodes the device walks reach every triangle exactly once
+ * and their single-precision boxes contain the tree's.  stats = {reference nodes, reference depth, surface-area nodes,
  * surface-area depth, leaves, largest leaf}.  RT_OK, or RT_ERR_* with rt_last_error(). */
 int32_t rt_check_tree(const double* tri_pos, int64_t count, int32_t leaf_size, double pad, int64_t stats[6]);
 

@@ -16,6 +16,7 @@
 #include <map>
 #include <memory>
 #include <unordered_map>
+#include <utility>
 #include <stdexcept>
 #include <string>
 #include <tuple>
@@ -188,7 +189,7 @@ struct rt_tracer
     std::vector<std::unique_ptr<GatherCache>> gatherCache;
 
     rtd::SceneView view{};
-    int blocks = 0;
+    int computeUnits = 0;
 };
 
 namespace
@@ -207,12 +208,6 @@ void buildScene(rt_tracer* t, const rt_scene* scene)
     std::vector<rtd::Node> nodes;
     std::vector<double> triRec, triNrm;
     std::vector<int32_t> triId;
-    // RT_AMD_TREE=reference keeps the reference's own median-split trees (for comparison runs);
-    // the default is the surface-area tree over the same triangles, which returns the same hits.
-    const char* treeChoice = std::getenv("RT_AMD_TREE");
-    const bool referenceTree = treeChoice != nullptr && std::strcmp(treeChoice, "reference") == 0;
-    require(treeChoice == nullptr || referenceTree || std::strcmp(treeChoice, "surface-area") == 0,
-            "RT_AMD_TREE must be 'reference' or 'surface-area'");
     int leafSize = 4;
     if (const char* leaf = std::getenv("RT_AMD_LEAF"))
     {
@@ -258,6 +253,7 @@ void buildScene(rt_tracer* t, const rt_scene* scene)
     {
         int32_t nodeBase, nodeCount;
         int64_t triBase;
+        double extent;
     };
     std::vector<MeshSpan> spans;
     int maxDepth = 1;
@@ -267,59 +263,53 @@ void buildScene(rt_tracer* t, const rt_scene* scene)
         require(mesh.first_triangle >= 0 && mesh.triangle_count >= 0 &&
                     mesh.first_triangle + mesh.triangle_count <= scene->triangle_count,
                 "mesh triangle range out of bounds");
-        require(mesh.triangle_count < (1ll << 30), "mesh too large");
+        require(mesh.triangle_count < (1ll << 26), "mesh too large");
         const double* pos = scene->tri_pos + 9 * mesh.first_triangle;
         const double* nrm = scene->tri_nrm + 9 * mesh.first_triangle;
-        rtbvh::FlatMesh flat = rtbvh::build(pos, mesh.triangle_count);
-        if (!referenceTree)
+        // the reference's tree gives every triangle its visiting rank and node box; the tree the
+        // device walks is built over the same triangles.  Padding: far above the rounding of a slab
+        // test on coordinates of this size, far below anything that would cost traversal steps.
+        double extent = 0.0;
+        for (int64_t i = 0; i < 9 * mesh.triangle_count; ++i)
         {
-            // padding: far above the rounding of a slab test on coordinates of this size, far
-            // below anything that would cost traversal steps
-            double extent = 0.0;
-            for (int64_t i = 0; i < 9 * mesh.triangle_count; ++i)
-            {
-                extent = std::max(extent, std::fabs(pos[i]));
-            }
-            const double pad = 1e-7 * extent + 1e-10 * sceneScale;
-            flat = rtbvh::buildSurfaceArea(pos, mesh.triangle_count, flat, pad, leafSize);
+            extent = std::max(extent, std::fabs(pos[i]));
         }
-        maxDepth = std::max(maxDepth, flat.depth);
+        const double pad = 1e-7 * extent + 1e-10 * sceneScale;
+        const rtbvh::FlatMesh flat =
+            rtbvh::buildSurfaceArea(pos, mesh.triangle_count, rtbvh::build(pos, mesh.triangle_count), pad, leafSize);
+        const rtbvh::WideMesh wide = rtbvh::widen(flat);
+        maxDepth = std::max(maxDepth, wide.pushDepth);
         if (std::getenv("RT_AMD_VERBOSE"))
         {
-            std::fprintf(stderr, "[rt_amd] mesh %lld: %lld triangles, %zu nodes, depth %d (%s tree)\n",
-                         static_cast<long long>(m), static_cast<long long>(mesh.triangle_count), flat.nodes.size(),
-                         flat.depth, referenceTree ? "reference" : "surface-area");
+            std::fprintf(stderr, "[rt_amd] mesh %lld: %lld triangles, %zu inner nodes, %d levels of them\n",
+                         static_cast<long long>(m), static_cast<long long>(mesh.triangle_count), wide.nodes.size(),
+                         wide.pushDepth);
         }
         MeshSpan span;
         span.nodeBase = static_cast<int32_t>(nodes.size());
-        span.nodeCount = static_cast<int32_t>(flat.nodes.size());
+        span.nodeCount = static_cast<int32_t>(wide.nodes.size());
         span.triBase = static_cast<int64_t>(triId.size());
-        for (const rtbvh::FlatNode& fn : flat.nodes)
+        span.extent = extent;
+        for (const rtbvh::WideNode& wn : wide.nodes)
         {
             rtd::Node n;
-            std::memcpy(n.bmin, fn.bmin, sizeof(n.bmin));
-            std::memcpy(n.bmax, fn.bmax, sizeof(n.bmax));
-            n.skip = fn.skip;
-            n.triStart = fn.triStart;
-            n.triCount = fn.triCount;
-            n.right = fn.right;
+            static_assert(sizeof(n) == sizeof(wn), "host and device node layouts differ");
+            std::memcpy(&n, &wn, sizeof(n));
             nodes.push_back(n);
         }
         for (size_t slot = 0; slot < flat.order.size(); ++slot)
         {
             const int32_t original = flat.order[slot];
             const double* p = pos + 9 * original;
-            // One 128-byte record per triangle: vertices, the box of its reference node, and one
-            // word holding its reference rank (low half) and, as a float, the smallest barycentric
+            // One 128-byte record per triangle: vertices, one word, the box of its reference node.  The
+            // word holds its reference rank (low half) and, as a float, the smallest barycentric
             // weight from which a hit is certain to pass the reference's slab test on that box
             // without running it (high half).  A hit point with weights >= w lies at least
             // w x (the triangle's extent along k) inside the box along every axis k the triangle
             // extends in, and that has to exceed the few-ulp relative rounding of the slab
             // parameters, i.e. ~1e-15 x the scene's coordinate scale; the constant below leaves four
-            // orders of magnitude.  With the reference's own tree every reached triangle is
-            // admitted by construction (-1 admits any weight).
-            float certain = -1.0f;
-            if (!referenceTree)
+            // orders of magnitude.
+            float certain;
             {
                 double narrowest = std::numeric_limits<double>::infinity();
                 for (int k = 0; k < 3; ++k)
@@ -337,8 +327,8 @@ void buildScene(rt_tracer* t, const rt_scene* scene)
             double wordAsDouble;
             std::memcpy(&wordAsDouble, &word, sizeof(word));
             triRec.insert(triRec.end(), p, p + 9);
-            triRec.insert(triRec.end(), flat.referenceBox.begin() + 6 * slot, flat.referenceBox.begin() + 6 * slot + 6);
             triRec.push_back(wordAsDouble);
+            triRec.insert(triRec.end(), flat.referenceBox.begin() + 6 * slot, flat.referenceBox.begin() + 6 * slot + 6);
             triNrm.insert(triNrm.end(), nrm + 9 * original, nrm + 9 * original + 9);
             triId.push_back(original);
         }
@@ -366,6 +356,7 @@ void buildScene(rt_tracer* t, const rt_scene* scene)
             v.nodeBase = spans[rv.mesh].nodeBase;
             v.nodeCount = spans[rv.mesh].nodeCount;
             v.triBase = spans[rv.mesh].triBase;
+            v.extent = spans[rv.mesh].extent;
         }
         else
         {
@@ -567,7 +558,7 @@ void buildScene(rt_tracer* t, const rt_scene* scene)
     view.windowEnd = windowEnd;
     view.hasCamera = scene->camera_count > 0 ? 1 : 0;
     require(maxDepth <= 48, "mesh tree too deep for the traversal stack");
-    view.stackDepth = maxDepth + 1;
+    view.stackDepth = std::max(1, maxDepth);
     view.patches = t->patches.ptr;
     view.patchCount = static_cast<int32_t>(patches.size());
     view.frameTime = start;
@@ -948,6 +939,63 @@ int32_t rt_check_tree(const double* tri_pos, int64_t count, int32_t leaf_size, d
             require(triangleInside(tree.order[slot], &tree.referenceBox[6 * slot], &tree.referenceBox[6 * slot + 3], 0.0),
                     "reference box does not contain its triangle");
         }
+        // the walk's nodes: every child box contains the tree node's (padded) box; following the
+        // references from the root reaches every leaf's slots exactly once
+        const rtbvh::WideMesh wide = rtbvh::widen(tree);
+        require(!wide.nodes.empty(), "walk has no root");
+        {
+            std::vector<char> slotSeen(n, 0);
+            std::vector<std::pair<int32_t, int>> pending{{0, 1}};  // (reference, inner levels so far)
+            std::vector<char> nodeSeen(wide.nodes.size(), 0);
+            int deepest = 0;
+            while (!pending.empty())
+            {
+                const auto [ref, level] = pending.back();
+                pending.pop_back();
+                if (ref == rtbvh::kNoChild) continue;
+                if (ref < 0)
+                {
+                    const int32_t packed = -1 - ref;
+                    const int32_t start = packed >> rtbvh::kLeafCountBits;
+                    const int32_t countHere = (packed & ((1 << rtbvh::kLeafCountBits) - 1)) + 1;
+                    for (int32_t slot = start; slot < start + countHere; ++slot)
+                    {
+                        require(slot >= 0 && static_cast<size_t>(slot) < n && !slotSeen[static_cast<size_t>(slot)],
+                                "leaf reference out of range or repeated");
+                        slotSeen[static_cast<size_t>(slot)] = 1;
+                    }
+                    continue;
+                }
+                require(static_cast<size_t>(ref) < wide.nodes.size() && !nodeSeen[static_cast<size_t>(ref)],
+                        "node reference out of range or repeated");
+                nodeSeen[static_cast<size_t>(ref)] = 1;
+                deepest = std::max(deepest, level);
+                const rtbvh::WideNode& node = wide.nodes[static_cast<size_t>(ref)];
+                pending.push_back({node.left, level + 1});
+                pending.push_back({node.right, level + 1});
+            }
+            for (size_t slot = 0; slot < n; ++slot) require(slotSeen[slot], "a triangle is not reachable");
+            require(deepest <= std::max(1, wide.pushDepth), "stack depth understated");
+            // boxes: walk both trees in step (inner tree nodes in preorder are the wide nodes in order)
+            size_t wideAt = 0;
+            for (size_t i = 0; i < tree.nodes.size(); ++i)
+            {
+                const rtbvh::FlatNode& node = tree.nodes[i];
+                if (node.skip == static_cast<int32_t>(i) + 1) continue;
+                const rtbvh::WideNode& w = wide.nodes[wideAt++];
+                const rtbvh::FlatNode* kids[2] = {&tree.nodes[i + 1], &tree.nodes[static_cast<size_t>(node.right)]};
+                const float* boxes[2] = {w.leftBox, w.rightBox};
+                for (int c = 0; c < 2; ++c)
+                {
+                    for (int k = 0; k < 3; ++k)
+                    {
+                        require(static_cast<double>(boxes[c][k]) <= kids[c]->bmin[k] &&
+                                    static_cast<double>(boxes[c][3 + k]) >= kids[c]->bmax[k],
+                                "single-precision box does not contain the tree's box");
+                    }
+                }
+            }
+        }
         stats[0] = static_cast<int64_t>(reference.nodes.size());
         stats[1] = reference.depth;
         stats[2] = static_cast<int64_t>(tree.nodes.size());
@@ -978,7 +1026,7 @@ int32_t rt_create(const rt_scene* scene, int32_t device, rt_tracer** out)
         buildScene(t.get(), scene);
         hipDeviceProp_t prop{};
         check(hipGetDeviceProperties(&prop, device), "hipGetDeviceProperties");
-        t->blocks = prop.multiProcessorCount * rtd::traceBlocksPerCu(t->view);
+        t->computeUnits = prop.multiProcessorCount;
         resetState(t.get());
         check(hipStreamSynchronize(t->stream), "hipStreamSynchronize");
         *out = t.release();
@@ -1287,15 +1335,17 @@ int32_t rt_trace(rt_tracer* tracer, const rt_trace_params* params)
             args.emissionOrder = tracer->sortOrder.ptr;
         }
         check(hipEventRecord(tracer->stageEvents[1], tracer->stream), "hipEventRecord");
+        // the persistent grid fills the chip with the variant this pass runs
+        const int residentBlocks = tracer->computeUnits * rtd::traceBlocksPerCu(args);
         // every resident wave should see several chunks: small passes use small chunks
         {
-            const uint64_t waves = static_cast<uint64_t>(tracer->blocks) * 4;
+            const uint64_t waves = static_cast<uint64_t>(residentBlocks) * 4;
             uint64_t chunk = args.totalWork / (waves * 4);
             chunk = std::min<uint64_t>(4096, std::max<uint64_t>(64, chunk)) & ~63ull;
             args.chunk = static_cast<uint32_t>(chunk);
         }
         const uint64_t wavesNeeded = (args.totalWork + 63) / 64;
-        const int blocks = static_cast<int>(std::min<uint64_t>(static_cast<uint64_t>(tracer->blocks), (wavesNeeded + 3) / 4));
+        const int blocks = static_cast<int>(std::min<uint64_t>(static_cast<uint64_t>(residentBlocks), (wavesNeeded + 3) / 4));
         rtd::launchTrace(args, std::max(1, blocks), 256, tracer->stream);
         check(hipGetLastError(), "trace launch");
         check(hipEventRecord(tracer->stageEvents[2], tracer->stream), "hipEventRecord");

@@ -1,7 +1,7 @@
 #include "rt_bvh.h"
 
 #include <algorithm>
-#include <cstdlib>
+#include <cmath>
 #include <limits>
 
 namespace rtbvh
@@ -308,14 +308,11 @@ FlatMesh buildSurfaceArea(const double* tri_pos, int64_t count, const FlatMesh& 
     b.pos = tri_pos;
     b.pad = pad;
     b.leafSize = std::max(1, leaf_size);
-    // Depth is LDS: every level is one traversal-stack entry per lane.  Small meshes get room for
-    // uneven splits (up to 15 levels in all); beyond that only two levels above a balanced tree.
+    // Depth is LDS: every level of inner nodes is one traversal-stack entry per lane.  Small meshes
+    // get room for uneven splits (up to 17 levels in all, 16 of them inner); beyond that only two
+    // levels above a balanced tree.
     const int balanced = 1 + SurfaceAreaBuilder::levelsFor(count, b.leafSize);
-    b.maxDepth = std::min(44, std::max(balanced + 2, std::min(balanced + 6, 15)));
-    if (const char* slack = std::getenv("RT_AMD_DEPTH_SLACK"))
-    {
-        b.maxDepth = std::min(44, balanced + std::max(0, std::atoi(slack)));
-    }
+    b.maxDepth = std::min(44, std::max(balanced + 2, std::min(balanced + 6, 17)));
     b.lo.resize(static_cast<size_t>(3 * count));
     b.hi.resize(static_cast<size_t>(3 * count));
     b.mid.resize(static_cast<size_t>(3 * count));
@@ -353,6 +350,83 @@ FlatMesh buildSurfaceArea(const double* tri_pos, int64_t count, const FlatMesh& 
         const FlatNode& node = reference.nodes[static_cast<size_t>(nodeOf[static_cast<size_t>(original)])];
         out.referenceBox.insert(out.referenceBox.end(), node.bmin, node.bmin + 3);
         out.referenceBox.insert(out.referenceBox.end(), node.bmax, node.bmax + 3);
+    }
+    return out;
+}
+
+namespace
+{
+
+float roundDown(double v)
+{
+    float f = static_cast<float>(v);
+    if (static_cast<double>(f) > v) f = std::nextafter(f, -std::numeric_limits<float>::infinity());
+    return f;
+}
+
+float roundUp(double v)
+{
+    float f = static_cast<float>(v);
+    if (static_cast<double>(f) < v) f = std::nextafter(f, std::numeric_limits<float>::infinity());
+    return f;
+}
+
+}  // namespace
+
+WideMesh widen(const FlatMesh& tree)
+{
+    WideMesh out;
+    const size_t count = tree.nodes.size();
+    auto isLeaf = [&](size_t i) { return tree.nodes[i].skip == static_cast<int32_t>(i) + 1; };
+    // inner nodes keep their preorder
+    std::vector<int32_t> wideIndex(count, -1);
+    int32_t inner = 0;
+    for (size_t i = 0; i < count; ++i)
+    {
+        if (!isLeaf(i)) wideIndex[i] = inner++;
+    }
+    auto reference = [&](size_t i) {
+        const FlatNode& node = tree.nodes[i];
+        if (!isLeaf(i)) return wideIndex[i];
+        return node.triCount > 0 ? leafReference(node.triStart, node.triCount) : kNoChild;
+    };
+    auto setBox = [&](float* box, const FlatNode& node) {
+        for (int k = 0; k < 3; ++k)
+        {
+            box[k] = roundDown(node.bmin[k]);
+            box[3 + k] = roundUp(node.bmax[k]);
+        }
+    };
+    if (count == 0 || isLeaf(0))
+    {
+        // a mesh that fits one leaf (or has no triangles): a root whose only child is that leaf
+        WideNode root{};
+        root.left = root.right = kNoChild;
+        if (count > 0)
+        {
+            root.left = reference(0);
+            setBox(root.leftBox, tree.nodes[0]);
+        }
+        out.nodes.push_back(root);
+        out.pushDepth = 0;
+        return out;
+    }
+    out.nodes.resize(static_cast<size_t>(inner));
+    // depth of inner nodes along the deepest path = entries the stack may hold
+    std::vector<int> level(count, 0);
+    for (size_t i = 0; i < count; ++i)
+    {
+        if (isLeaf(i)) continue;
+        const FlatNode& node = tree.nodes[i];
+        const size_t left = i + 1, right = static_cast<size_t>(node.right);
+        WideNode wide{};
+        wide.left = reference(left);
+        wide.right = reference(right);
+        setBox(wide.leftBox, tree.nodes[left]);
+        setBox(wide.rightBox, tree.nodes[right]);
+        out.nodes[static_cast<size_t>(wideIndex[i])] = wide;
+        level[left] = level[right] = level[i] + 1;
+        out.pushDepth = std::max(out.pushDepth, level[i] + 1);
     }
     return out;
 }

@@ -9,6 +9,7 @@
 // order, which is what breaks ties between equally distant hits.
 #pragma once
 
+#include <climits>
 #include <cstdint>
 #include <vector>
 
@@ -50,5 +51,30 @@ FlatMesh build(const double* tri_pos, int64_t count);
 // triangle meets the padded box that holds it whatever the rounding); `rank` and
 // `referenceBox` let the walk apply the reference's admission test and tie-break per hit.
 FlatMesh buildSurfaceArea(const double* tri_pos, int64_t count, const FlatMesh& reference, double pad, int leaf_size);
+
+// The surface-area tree as the device walks it: inner nodes only, each holding BOTH children's
+// boxes (single precision, rounded outward — the boxes only have to contain, see above) and a
+// reference per child: >= 0 the index of an inner node, kNoChild, or a leaf as
+// leafReference(first slot, count).  One 64-byte node per walk step, nothing to fetch for a leaf.
+struct WideNode
+{
+    float leftBox[6];   // min xyz, max xyz
+    float rightBox[6];
+    int32_t left, right;
+    int32_t reserved[2];
+};
+static_assert(sizeof(WideNode) == 64, "one node per 64-byte line");
+
+constexpr int32_t kNoChild = INT32_MIN;
+constexpr int kLeafCountBits = 4;  // up to 16 triangles per leaf
+inline int32_t leafReference(int32_t first, int32_t count) { return -1 - ((first << kLeafCountBits) | (count - 1)); }
+
+struct WideMesh
+{
+    std::vector<WideNode> nodes;  // node 0 is the root (present even for an empty mesh)
+    int pushDepth = 0;            // most entries the walk's stack can hold at once
+};
+
+WideMesh widen(const FlatMesh& tree);
 
 }  // namespace rtbvh

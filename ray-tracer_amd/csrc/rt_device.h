@@ -24,6 +24,8 @@
 // lanes of the traversal loops, printed when a tracer is destroyed.
 #ifdef RT_DIAG
 __device__ unsigned long long g_rtDiag[16];
+#endif
+#if defined(RT_DIAG) && RT_DIAG == 1
 #define RT_DIAG_TRIP(slot)                                                                     \
     do                                                                                         \
     {                                                                                          \
@@ -34,18 +36,41 @@ __device__ unsigned long long g_rtDiag[16];
             atomicAdd(&g_rtDiag[(slot) + 1], static_cast<unsigned long long>(__builtin_popcountll(diagMask))); \
         }                                                                                      \
     } while (0)
-// cycles spent by a wave between RT_DIAG_TIC and RT_DIAG_TOC, summed into g_rtDiag[slot]
-#define RT_DIAG_TIC const long long diagStart = __builtin_readcyclecounter()
-#define RT_DIAG_TOC(slot)                                                                       \
-    do                                                                                          \
-    {                                                                                           \
-        const long long diagCycles = __builtin_readcyclecounter() - diagStart;                 \
-        if ((threadIdx.x & 63) == 0) atomicAdd(&g_rtDiag[slot], static_cast<unsigned long long>(diagCycles)); \
-    } while (0)
 #else
 #define RT_DIAG_TRIP(slot) do { } while (0)
-#define RT_DIAG_TIC do { } while (0)
-#define RT_DIAG_TOC(slot) do { } while (0)
+#endif
+// Cycle census (build with -DRT_DIAG=2): wave cycles between RT_DIAG_TIC(name) and
+// RT_DIAG_TOC(name, slot), summed per wave in LDS while the kernel runs and added to
+// g_rtDiag[slot] at its end (per-trip global atomics would dominate what they measure).
+#if defined(RT_DIAG) && RT_DIAG == 2
+__device__ __forceinline__ unsigned long long* rtDiagWaveSlots()
+{
+    __shared__ unsigned long long rtDiagCycles[4 * 16];
+    return rtDiagCycles + 16 * (threadIdx.x >> 6);
+}
+#define RT_DIAG_TIC(name) const long long name = __builtin_readcyclecounter()
+#define RT_DIAG_TOC(name, slot)                                                                 \
+    do                                                                                          \
+    {                                                                                           \
+        const long long diagCycles = __builtin_readcyclecounter() - name;                      \
+        if (static_cast<int>(threadIdx.x & 63) == __builtin_ctzll(__ballot(1)))                \
+            rtDiagWaveSlots()[slot] += static_cast<unsigned long long>(diagCycles);            \
+    } while (0)
+#define RT_DIAG_WAVE_BEGIN                                                                      \
+    do                                                                                          \
+    {                                                                                           \
+        if ((threadIdx.x & 63) < 16) rtDiagWaveSlots()[threadIdx.x & 63] = 0;                  \
+    } while (0)
+#define RT_DIAG_WAVE_END                                                                        \
+    do                                                                                          \
+    {                                                                                           \
+        if ((threadIdx.x & 63) < 16) atomicAdd(&g_rtDiag[threadIdx.x & 63], rtDiagWaveSlots()[threadIdx.x & 63]); \
+    } while (0)
+#else
+#define RT_DIAG_TIC(name) do { } while (0)
+#define RT_DIAG_TOC(name, slot) do { } while (0)
+#define RT_DIAG_WAVE_BEGIN do { } while (0)
+#define RT_DIAG_WAVE_END do { } while (0)
 #endif
 
 namespace rtd
@@ -117,26 +142,27 @@ RT_DEV Color operator*(const Color& a, const Color& b) { return Color{a.r * b.r,
 RT_DEV float brightness(const Color& c) { return c.r + c.g + c.b; }
 
 // ------------------------------------------------------------------ flattened scene
-// One node of a mesh's tree, stored in the reference's visiting order (node page, left
-// subtree, right subtree — src/Tree.cpp:207-237).  `skip` is the index of the next
-// node in that order once this node's subtree is left out; the left child, when there
-// is one, is the next node, and `right` is the right child (-1: none).
+// One inner node of a mesh's tree (leaves are not stored): both children's boxes in single
+// precision, rounded outward, and one reference per child — the index of an inner node when
+// >= 0, kNoChild, or a leaf's triangle slots packed as -1 - (first * 16 + count - 1).  The
+// boxes only decide which triangles are reached; which hit is reported is decided per
+// triangle (SceneView::triRec), so they need to contain, not to match the reference's.
 struct Node
 {
-    double bmin[3];
-    double bmax[3];
-    int32_t skip;
-    int32_t triStart;  // into the mesh's page-ordered triangle arrays
-    int32_t triCount;
-    int32_t right;
+    float leftBox[6];  // min xyz, max xyz
+    float rightBox[6];
+    int32_t left, right;
+    int32_t reserved[2];
 };
 static_assert(sizeof(Node) == 64, "Node must be one 64-byte line");
+constexpr int32_t kNoChild = static_cast<int32_t>(0x80000000u);
 
 struct Volume
 {
     int32_t type, material, nodeBase, nodeCount;
     int64_t triBase;  // first triangle of the mesh in the page-ordered arrays
     int32_t animation, pad;  // index into SceneView::animations, or -1 for a static volume
+    double extent;           // largest |coordinate| of the mesh (scale of the pruning slack)
     double pos[3];
     Quat rot, inv;    // rotation and Quaternion::inverse() of it (src/Quaternion.cpp:49-52)
     double param[18];
@@ -197,10 +223,10 @@ struct SceneView
 {
     const Volume* volumes;
     const Node* nodes;
-    // [16 * T], one 128-byte record per triangle slot: vertices a b c (9), the box of the
-    // reference node whose page holds the triangle (6), and a word with the triangle's rank in the
-    // reference's visiting order (low half) and the barycentric weight from which a hit is
-    // certainly admitted by that box (float, high half)
+    // [16 * T], one 128-byte record per triangle slot: vertices a b c (9), a word with the
+    // triangle's rank in the reference's visiting order (low half) and the barycentric weight
+    // from which a hit is certainly admitted by the reference's box (float, high half), then that
+    // box: min xyz, max xyz of the reference node whose page holds the triangle (6)
     const double* triRec;
     const double* triNrm;  // [9 * T] page order
     const int32_t* triId;  // slot -> index within the mesh (load order)
@@ -209,7 +235,7 @@ struct SceneView
     Camera* cameras;
     const EmitterPatch* patches;
     int32_t patchCount;
-    int32_t stackDepth;  // traversal stack entries per lane (deepest tree + 1)
+    int32_t stackDepth;  // traversal stack entries per lane (inner levels of the deepest tree)
     int32_t volumeCount, lightCount, cameraCount, bounceThreshold;
     int32_t materialCount, meshVolumeCount;
     double terminationThreshold;
@@ -380,7 +406,8 @@ RT_DEV bool edgeAccept(double value, double ex, double ey)  // src/Ray.cpp:190-2
 // Watertight ray/triangle test, src/Ray.cpp:85-247.  On a hit writes the barycentric
 // weights, the reconstructed position and the Euclidean distance.  `tp` points at the
 // nine vertex coordinates in memory; the sheared coordinates need the vertices in the
-// ray's permuted axis order, which is read straight from memory by index.
+// ray's permuted axis order, which is read straight from memory by index (selecting among
+// registers after wide loads of the record was measured 10 % slower for the whole kernel).
 RT_DEV bool rayIntersectsTriangle(const Ray& ray, const RayPrep& p, const double* tp, double* bary, Vec* position,
                                   double* distance)
 {
@@ -546,22 +573,46 @@ RT_DEV TraversalStack laneStack()
     return TraversalStack{rtTraversalStack + threadIdx.x, static_cast<int32_t>(blockDim.x)};
 }
 
+// Slab test of one child box of a node (six floats, widened exactly): the same interval
+// arithmetic as slabTest; the plane the ray meets first is picked by the direction's sign.
+RT_DEV bool slabTestChild(const Ray& ray, const RayPrep& p, const float* box, double* entry)
+{
+    double tmin = 0.0;
+    double tmax = kMaxDouble;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+    {
+        const double origin = axisOf(ray.o, i);
+        const bool reversed = p.nearIdx[i] != i;
+        const float nearPlane = reversed ? box[3 + i] : box[i];
+        const float farPlane = reversed ? box[i] : box[3 + i];
+        const double tnear = (static_cast<double>(nearPlane) - origin) * p.ood[i];
+        const double tfar = (static_cast<double>(farPlane) - origin) * p.ood[i];
+        tmin = __builtin_fmax(tmin, tnear);
+        tmax = __builtin_fmin(tmax, tfar);
+    }
+    *entry = tmin;
+    return !(tmin > tmax);
+}
+
 // Closest hit of one mesh, equal to Tree::castRay's exhaustive minimum
 // (src/Tree.cpp:133-152,207-237).  The reference visits every node whose box (and
 // whose ancestors' boxes) the ray meets, in page / left / right order, and keeps a
 // candidate only when it is strictly closer, so of equally distant hits the one
-// visited first wins.  Every triangle carries its rank in that visiting order (its slot
-// itself when the tree is the reference's own), so the same winner is "smallest distance,
-// then smallest rank" — which no longer depends on the order of the walk, nor on the
-// shape of the tree as long as the walk reaches every triangle the reference would test
-// and admits only those (see SceneView::triRec).  That frees the walk to go near child first and to leave out any
-// subtree the ray enters beyond the best distance so far (or beyond `bound`, the
-// distance another volume has already achieved): such a subtree cannot hold a hit
-// that wins.  The comparison carries a margin far above the rounding of the box
-// parameter and of the reconstructed hit distance, so ties and near-ties are always
-// visited.  Triangle tests are deferred until every lane of the wave has either
-// reached a node with triangles or run out of nodes, so that the lanes test
-// triangles together instead of one lane at a time.
+// visited first wins.  Every triangle carries its rank in that visiting order and the
+// box of the reference node that holds it (SceneView::triRec), so the same winner is
+// "of the triangles the reference would test, the one at the smallest distance, then of
+// the smallest rank" — which depends neither on the order of the walk nor on the shape of
+// the tree, as long as the walk reaches every such triangle.  That frees the walk to use
+// its own tree, to go near child first and to leave out any subtree the ray enters beyond
+// the best distance so far (or beyond `bound`, the distance another volume has already
+// achieved): such a subtree cannot hold a hit that wins.  The comparison carries a margin
+// far above the rounding of the box parameter and of the reconstructed hit distance, so
+// ties and near-ties are always visited.  A step reads one 64-byte node — both children's
+// boxes and references — and a leaf is a reference, not a node, so its triangles follow
+// without another fetch.  Triangle tests are deferred until every lane of the wave has
+// either reached a leaf or run out of nodes, so that the lanes test triangles together
+// instead of one lane at a time.
 RT_DEV bool castMesh(const SceneView& s, const Volume& vol, const Ray& ray, const RayPrep& prep,
                      const TraversalStack& stack, double bound, double* bary, Vec* position, double* distance,
                      int32_t* triSlot)
@@ -574,72 +625,56 @@ RT_DEV bool castMesh(const SceneView& s, const Volume& vol, const Ray& ray, cons
     const Node* nodes = s.nodes + vol.nodeBase;
     const double* triRec = s.triRec + 16 * vol.triBase;
     const double dlen = magnitude(ray.d);
-    const Node& root = nodes[0];
-    double extent = 0.0;
-#pragma unroll
-    for (int k = 0; k < 3; ++k)
-    {
-        extent = dmax(extent, dmax(dabs(root.bmin[k]), dabs(root.bmax[k])));
-    }
-    const double slack = 1e-11 * (extent + dabs(ray.o.x) + dabs(ray.o.y) + dabs(ray.o.z));
+    const double slack = 1e-11 * (vol.extent + dabs(ray.o.x) + dabs(ray.o.y) + dabs(ray.o.z));
     bool found = false;
     double best = kMaxDouble;
     int32_t bestSlot = 0x7fffffff, bestRank = 0x7fffffff;
     double cutoff = bound * (1.0 + 1e-9) + slack;  // kMaxDouble -> +inf: nothing is pruned
 
-    double rootEntry;
-    if (!slabTest(ray, prep, root.bmin, &rootEntry) || rootEntry * dlen > cutoff)
-    {
-        return false;
-    }
-    int32_t cur = 0;
+    constexpr int32_t kDone = kNoChild;    // nothing left to visit
+    constexpr int32_t kPop = kNoChild + 1;  // take the next entry of the stack
+    int32_t cur = 0;                        // >= 0 inner node, kDone, kPop, else a leaf reference
     int32_t sp = 0;
-    bool tested = false;  // the triangles of `cur` were tested already
     while (true)
     {
         RT_DIAG_TRIP(2);  // outer rounds
-        int32_t pendingStart = 0, pendingEnd = 0;
-        while (cur >= 0)
+        RT_DIAG_TIC(nodeLoopStart);
+        while (true)
         {
             RT_DIAG_TRIP(4);  // node steps
-            const Node& node = nodes[cur];
-            const int32_t skip = node.skip, triStart = node.triStart, triCount = node.triCount, right = node.right;
-            if (triCount > 0 && !tested)
+            if (cur >= 0)
             {
-                pendingStart = triStart;
-                pendingEnd = triStart + triCount;
-                break;
+                const Node& node = nodes[cur];
+                const float4 q0 = reinterpret_cast<const float4*>(&node)[0];
+                const float4 q1 = reinterpret_cast<const float4*>(&node)[1];
+                const float4 q2 = reinterpret_cast<const float4*>(&node)[2];
+                const int4 links = reinterpret_cast<const int4*>(&node)[3];
+                const float leftBox[6] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y};
+                const float rightBox[6] = {q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
+                const int32_t left = links.x, right = links.y;
+                double el, er;
+                bool okl = slabTestChild(ray, prep, leftBox, &el);
+                bool okr = slabTestChild(ray, prep, rightBox, &er);
+                okl = okl && left != kNoChild && !(el * dlen > cutoff);
+                okr = okr && right != kNoChild && !(er * dlen > cutoff);
+                if (okl && okr)
+                {
+                    const bool leftNear = el <= er;
+                    const int32_t farChild = leftNear ? right : left;
+                    const float farEntry = __double2float_rd(leftNear ? er : el);
+                    stack.base[sp * stack.stride] =
+                        (static_cast<unsigned long long>(static_cast<uint32_t>(farChild)) << 32) | __float_as_uint(farEntry);
+                    sp += 1;
+                    cur = leftNear ? left : right;
+                }
+                else
+                {
+                    cur = okl ? left : (okr ? right : kPop);
+                }
             }
-            tested = false;
-            // children: the left one, if any, follows the node; both boxes are fetched
-            // and tested by every lane (absent children re-test the node itself)
-            const int32_t first = cur + 1;
-            const bool hasLeft = skip > first && right != first;
-            const bool hasRight = right >= 0;
-            const Node& ln = nodes[hasLeft ? first : cur];
-            const Node& rn = nodes[hasRight ? right : cur];
-            double el, er;
-            bool okl = slabTest(ray, prep, ln.bmin, &el);
-            bool okr = slabTest(ray, prep, rn.bmin, &er);
-            okl = okl && hasLeft && !(el * dlen > cutoff);
-            okr = okr && hasRight && !(er * dlen > cutoff);
-            if (okl && okr)
+            if (cur == kPop)
             {
-                const bool leftNear = el <= er;
-                const int32_t farNode = leftNear ? right : first;
-                const float farEntry = __double2float_rd(leftNear ? er : el);
-                stack.base[sp * stack.stride] =
-                    (static_cast<unsigned long long>(static_cast<uint32_t>(farNode)) << 32) | __float_as_uint(farEntry);
-                sp += 1;
-                cur = leftNear ? first : right;
-            }
-            else if (okl || okr)
-            {
-                cur = okl ? first : right;
-            }
-            else
-            {
-                cur = -1;
+                cur = kDone;
                 while (sp > 0)
                 {
                     sp -= 1;
@@ -652,11 +687,20 @@ RT_DEV bool castMesh(const SceneView& s, const Volume& vol, const Ray& ray, cons
                     }
                 }
             }
+            if (cur < 0)
+            {
+                break;  // a leaf to test, or done
+            }
         }
-        if (cur < 0)
+        RT_DIAG_TOC(nodeLoopStart, 2);
+        if (cur == kDone)
         {
             break;
         }
+        const int32_t packed = -1 - cur;
+        const int32_t pendingStart = packed >> 4;
+        const int32_t pendingEnd = pendingStart + (packed & 15) + 1;
+        RT_DIAG_TIC(triLoopStart);
         for (int32_t t = pendingStart; t < pendingEnd; ++t)
         {
             RT_DIAG_TRIP(6);  // triangle tests
@@ -664,7 +708,7 @@ RT_DEV bool castMesh(const SceneView& s, const Volume& vol, const Ray& ray, cons
             Vec pos;
             const double* rec = triRec + 16 * t;
             // rank and admission weight travel with the vertices: same 128-byte line, same wait
-            const unsigned long long word = reinterpret_cast<const unsigned long long*>(rec)[15];
+            const unsigned long long word = reinterpret_cast<const unsigned long long*>(rec)[9];
             if (rayIntersectsTriangle(ray, prep, rec, b3, &pos, &d))
             {
                 const int32_t rank = static_cast<int32_t>(static_cast<uint32_t>(word));
@@ -679,7 +723,7 @@ RT_DEV bool castMesh(const SceneView& s, const Volume& vol, const Ray& ray, cons
                     if (prep.parallel || !(least >= certain))
                     {
                         double ignored;
-                        wins = slabTest(ray, prep, rec + 9, &ignored);
+                        wins = slabTest(ray, prep, rec + 10, &ignored);
                     }
                 }
                 if (wins)
@@ -696,7 +740,8 @@ RT_DEV bool castMesh(const SceneView& s, const Volume& vol, const Ray& ray, cons
                 }
             }
         }
-        tested = true;
+        RT_DIAG_TOC(triLoopStart, 3);
+        cur = kPop;
     }
     *triSlot = bestSlot;
     *distance = best;

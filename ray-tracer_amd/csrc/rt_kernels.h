@@ -98,7 +98,7 @@ void launchEmit(const SceneView& scene, int32_t light, int64_t n, const double* 
 void launchIntersect(int kind, int64_t n, const double* in, void* out, hipStream_t stream);
 void launchBsdfSample(int64_t n, const double* in14, double* out10, hipStream_t stream);
 void launchBsdfEvaluate(int64_t n, const double* in14, double* out4, hipStream_t stream);
-int traceBlocksPerCu(const SceneView& scene);
+int traceBlocksPerCu(const TraceArgs& args);
 #ifdef RT_DIAG
 void printDiagnostics();
 #endif

@@ -451,6 +451,8 @@ __global__ __launch_bounds__(kTraceThreads) void traceKernel(const TraceArgs a)
 {
     const SceneView& s = a.scene;
     const int lane = threadIdx.x & 63;
+    RT_DIAG_WAVE_BEGIN;
+    RT_DIAG_TIC(kernelStart);
 
     // this wave's chunk of photon ids, in emission order (LDS)
     extern __shared__ unsigned long long rtTraversalStack[];
@@ -482,6 +484,7 @@ __global__ __launch_bounds__(kTraceThreads) void traceKernel(const TraceArgs a)
         // ---- refill idle lanes (Worker::processLights + Light::emit) ----
         // two passes: when the current chunk runs out in the middle of a refill, the rest of
         // the lanes are served from the next chunk
+        RT_DIAG_TIC(refillStart);
 #pragma unroll 1
         for (int pass = 0; pass < 2; ++pass)
         {
@@ -562,6 +565,7 @@ __global__ __launch_bounds__(kTraceThreads) void traceKernel(const TraceArgs a)
                 }
             }
         }
+        RT_DIAG_TOC(refillStart, 4);
         if (__ballot(alive) == 0)
         {
             break;
@@ -580,7 +584,10 @@ __global__ __launch_bounds__(kTraceThreads) void traceKernel(const TraceArgs a)
             if (!done)
             {
                 casts += 1;
-                if (!castScene<Animated>(s, ray, time, kSelfHitThreshold, true, &hit))
+                RT_DIAG_TIC(castStart);
+                const bool hitSomething = castScene<Animated>(s, ray, time, kSelfHitThreshold, true, &hit);
+                RT_DIAG_TOC(castStart, 1);
+                if (!hitSomething)
                 {
                     done = true;  // escaped the scene
                 }
@@ -611,6 +618,7 @@ __global__ __launch_bounds__(kTraceThreads) void traceKernel(const TraceArgs a)
                     lc.power[1] += color.g;
                     lc.power[2] += color.b;
                 }
+                RT_DIAG_TIC(depositStart);
                 if (Sink == kSinkProbe)
                 {
                     bool keep = false;
@@ -632,6 +640,9 @@ __global__ __launch_bounds__(kTraceThreads) void traceKernel(const TraceArgs a)
                     }
                     splatToCamera<Animated>(a, ray.d, color, bounces, lightId, time, hit, material, lc);
                 }
+
+                RT_DIAG_TOC(depositStart, 5);
+                RT_DIAG_TIC(scatterStart);
 
                 // terminate: absolute decay floor or bounce cap (src/Worker.cpp:640-644,
                 // include/Photon.h:55-72)
@@ -660,6 +671,7 @@ __global__ __launch_bounds__(kTraceThreads) void traceKernel(const TraceArgs a)
                         color = color * smp.weight;
                     }
                 }
+                RT_DIAG_TOC(scatterStart, 6);
             }
             else
             {
@@ -682,6 +694,8 @@ __global__ __launch_bounds__(kTraceThreads) void traceKernel(const TraceArgs a)
     }
 
     // ---- flush counters: one atomic per wave per counter ----
+    RT_DIAG_TOC(kernelStart, 0);
+    RT_DIAG_WAVE_END;
     unsigned long long sums[12] = {lc.photons, lc.casts, lc.bounces, lc.deposits, lc.kept, lc.culled,
                                    lc.splatTotal, lc.splatRadiusClamped, lc.splatLuminanceClamped,
                                    lc.densityCells, lc.densityDeposits, lc.densityOverflow};
@@ -1417,12 +1431,21 @@ void printDiagnostics()
 {
     unsigned long long host[16] = {};
     if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_rtDiag), sizeof(host)) != hipSuccess) return;
+#if RT_DIAG == 2
+    const char* names[] = {"kernel", "casts", "node loops", "triangle loops", "refill", "deposit", "scatter"};
+    for (int k = 0; k < 7; ++k)
+    {
+        fprintf(stderr, "[rt diag] wave cycles  %-15s %16llu  (%.1f %% of the kernel)\n", names[k], host[k],
+                host[0] ? 100.0 * static_cast<double>(host[k]) / static_cast<double>(host[0]) : 0.0);
+    }
+#else
     const char* names[] = {"mesh casts", "outer rounds", "node steps", "triangle tests", "main loop", "keep tests"};
     for (int k = 0; k < 6; ++k)
     {
         fprintf(stderr, "[rt diag] %-15s wave trips %12llu  active lanes %14llu  (%.1f / 64)\n", names[k], host[2 * k],
                 host[2 * k + 1], host[2 * k] ? static_cast<double>(host[2 * k + 1]) / host[2 * k] : 0.0);
     }
+#endif
     unsigned long long zero[16] = {};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_rtDiag), zero, sizeof(zero));
 }
@@ -1434,41 +1457,57 @@ void launchEmissionTiles(const TraceArgs& args, uint32_t* order, hipStream_t str
     hipLaunchKernelGGL(emissionTileKernel, dim3(static_cast<unsigned>(tiles)), dim3(kTileThreads), 0, stream, args, order);
 }
 
-void launchTrace(const TraceArgs& args, int blocks, int threads, hipStream_t stream)
+namespace
 {
-    (void)threads;
-    const dim3 grid(blocks), block(kTraceThreads);
-    const size_t lds = stackBytes(args.scene, kTraceThreads) + (kTraceThreads / 64) * kSortBytesPerWave;
+
+// The kernel variant a pass runs: sink, per-photon records, keyframed volumes.
+typedef void (*TraceKernel)(const TraceArgs);
+
+TraceKernel traceVariant(const TraceArgs& args)
+{
     const bool record = args.records.recordPhotons > 0;
     const bool animated = args.scene.animationCount > 0;
     const int variant = (record ? 1 : 0) | (animated ? 2 : 0);
-#define RT_LAUNCH_TRACE(sink)                                                                                     \
-    switch (variant)                                                                                              \
-    {                                                                                                             \
-    case 0: hipLaunchKernelGGL((traceKernel<sink, false, false>), grid, block, lds, stream, args); break;         \
-    case 1: hipLaunchKernelGGL((traceKernel<sink, true, false>), grid, block, lds, stream, args); break;          \
-    case 2: hipLaunchKernelGGL((traceKernel<sink, false, true>), grid, block, lds, stream, args); break;          \
-    default: hipLaunchKernelGGL((traceKernel<sink, true, true>), grid, block, lds, stream, args); break;          \
+#define RT_TRACE_VARIANTS(sink)                                                  \
+    switch (variant)                                                             \
+    {                                                                            \
+    case 0: return traceKernel<sink, false, false>;                              \
+    case 1: return traceKernel<sink, true, false>;                               \
+    case 2: return traceKernel<sink, false, true>;                               \
+    default: return traceKernel<sink, true, true>;                               \
     }
     switch (args.sinkMode)
     {
-    case kSinkProbe: RT_LAUNCH_TRACE(kSinkProbe); break;
-    case kSinkSplat: RT_LAUNCH_TRACE(kSinkSplat); break;
-    default: RT_LAUNCH_TRACE(kSinkNone); break;
+    case kSinkProbe: RT_TRACE_VARIANTS(kSinkProbe)
+    case kSinkSplat: RT_TRACE_VARIANTS(kSinkSplat)
+    default: RT_TRACE_VARIANTS(kSinkNone)
     }
-#undef RT_LAUNCH_TRACE
+#undef RT_TRACE_VARIANTS
 }
 
-int traceBlocksPerCu(const SceneView& scene)
+size_t traceLdsBytes(const SceneView& scene)
+{
+    return stackBytes(scene, kTraceThreads) + (kTraceThreads / 64) * kSortBytesPerWave;
+}
+
+}  // namespace
+
+void launchTrace(const TraceArgs& args, int blocks, int threads, hipStream_t stream)
+{
+    (void)threads;
+    hipLaunchKernelGGL(traceVariant(args), dim3(blocks), dim3(kTraceThreads), traceLdsBytes(args.scene), stream, args);
+}
+
+// Resident blocks per CU of the variant this pass runs (registers and LDS differ between them;
+// the persistent grid is sized to exactly fill the chip).
+int traceBlocksPerCu(const TraceArgs& args)
 {
     int blocks = 0;
-    // the grid is sized by the variant with the largest register footprint
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, traceKernel<kSinkSplat, true, true>, kTraceThreads,
-                                                     stackBytes(scene, kTraceThreads) +
-                                                         (kTraceThreads / 64) * kSortBytesPerWave) != hipSuccess ||
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, traceVariant(args), kTraceThreads,
+                                                     traceLdsBytes(args.scene)) != hipSuccess ||
         blocks < 1)
     {
-        blocks = 2;
+        blocks = 1;
     }
     return blocks;
 }

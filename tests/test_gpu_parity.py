@@ -163,30 +163,25 @@ def test_photon_paths_bit_exact_vs_oracle(rt, scene_opener, name):
     assert np.allclose(counters["deposited_power"], ref["deposited_power"], rtol=1e-9)
 
 
-@pytest.mark.parametrize("name,photons", [("bombardment", 3_000_000), ("knot", 400_000), ("cbgmd", 400_000),
-                                          ("animated", 200_000)])
-def test_surface_area_tree_returns_reference_tree_hits(rt, scene_opener, name, photons, monkeypatch):
-    """The default tree (surface-area splits, padded boxes, several triangles per leaf) must report
-    exactly what a walk of the reference's own median-split tree reports: same counters over
-    millions of casts, and the same path bits and triangle ids for the recorded photons."""
+@pytest.mark.parametrize("name,photons", [("bombardment", 4_000_000), ("knot", 2_000_000), ("cbgmd", 1_500_000)])
+def test_counters_equal_oracle_at_scale(rt, scene_opener, name, photons):
+    """The device walks its own trees (surface-area splits, padded single-precision boxes, several
+    triangles per leaf) and must still report the hits of the reference's exhaustive walk of its
+    median-split trees, which is what the oracle runs: over this many casts every hit-or-miss
+    decision and every bounce count has to agree, so the pass counters are compared exactly."""
     entry = dict(SCENES[name], photons_per_light=photons)
-    results = {}
-    for tree in ("reference", "surface-area"):
-        monkeypatch.setenv("RT_AMD_TREE", tree)
-        scene = scene_opener(entry)
-        tracer = rt.Tracer(scene)
-        tracer.reset()
-        tracer.trace(sink_mode=0, record_photons=50_000)
-        results[tree] = (tracer.counters(), tracer.records())
-    (c0, r0), (c1, r1) = results["reference"], results["surface-area"]
+    scene, tracer, orc = _open(rt, scene_opener, entry)
+    tracer.reset()
+    tracer.trace(sink_mode=0, record_photons=20_000)
+    c = tracer.counters()
+    got = tracer.records()
+    ref = orc.trace(rng_mode=O.RNG_COUNTER, math_mode=O.MATH_PORTABLE, threads=8, record_photons=20_000)
     for k in ("photons", "casts", "bounces", "deposits"):
-        assert c0[k] == c1[k], k
-    assert c0["bounces"] > photons // 2
-    assert_bits_equal(r0["bounce_f64"], r1["bounce_f64"], "hits")
-    assert np.array_equal(r0["bounce_i32"], r1["bounce_i32"]), "ids"
-    assert np.array_equal(r0["casts_valid"], r1["casts_valid"])
-    assert_bits_equal(r0["bounce_power"], r1["bounce_power"], "power")
-    assert np.allclose(c0["deposited_power"], c1["deposited_power"], rtol=1e-12)
+        assert c[k] == ref[k], k
+    assert c["bounces"] > photons // 2
+    assert_bits_equal(got["bounce_f64"], ref["bounce_f64"], "hits")
+    assert np.array_equal(got["bounce_i32"], ref["bounce_i32"]), "ids"
+    assert np.allclose(c["deposited_power"], ref["deposited_power"], rtol=1e-9)
 
 
 def _sorted_records(store):
