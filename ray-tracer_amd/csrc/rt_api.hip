@@ -163,7 +163,7 @@ struct rt_tracer
     DeviceArray<unsigned long long> scalars;
     DeviceArray<rtd::DeviceCounters> counters;
     // emission-order list of a pass's photon ids
-    DeviceArray<uint32_t> sortOrder;
+    DeviceArray<uint32_t> tileOrder, sortOrder;
     // events around the stages of the last rt_trace: before the sort, after it, after the trace kernel
     hipEvent_t stageEvents[3] = {nullptr, nullptr, nullptr};
     bool timed = false;
@@ -1325,13 +1325,21 @@ int32_t rt_trace(rt_tracer* tracer, const rt_trace_params* params)
             if (e == nullptr) check(hipEventCreate(&e), "hipEventCreate");
         }
         check(hipEventRecord(tracer->stageEvents[0], tracer->stream), "hipEventRecord");
-        // large passes are traced in emission order (a schedule only; see emissionTileKernel)
+        // Passes are traced in emission order (a schedule only; see emissionTileKernel): large ones
+        // are first sorted coarsely tile by tile, then every window of 4096 positions finely.
         args.emissionOrder = nullptr;
-        if (args.totalWork >= (1ull << 20) && args.totalWork < (1ull << 32))
+        if (args.totalWork < (1ull << 32))
         {
             if (tracer->sortOrder.count < args.totalWork) tracer->sortOrder.allocate(args.totalWork);
-            rtd::launchEmissionTiles(args, tracer->sortOrder.ptr, tracer->stream);
-            check(hipGetLastError(), "emission sort launch");
+            if (args.totalWork >= (1ull << 20))
+            {
+                if (tracer->tileOrder.count < args.totalWork) tracer->tileOrder.allocate(args.totalWork);
+                rtd::launchEmissionTiles(args, tracer->tileOrder.ptr, tracer->stream);
+                check(hipGetLastError(), "emission tile sort launch");
+                args.emissionOrder = tracer->tileOrder.ptr;
+            }
+            rtd::launchChunkSort(args, tracer->sortOrder.ptr, tracer->stream);
+            check(hipGetLastError(), "emission window sort launch");
             args.emissionOrder = tracer->sortOrder.ptr;
         }
         check(hipEventRecord(tracer->stageEvents[1], tracer->stream), "hipEventRecord");

@@ -407,7 +407,8 @@ RT_DEV bool edgeAccept(double value, double ex, double ey)  // src/Ray.cpp:190-2
 // weights, the reconstructed position and the Euclidean distance.  `tp` points at the
 // nine vertex coordinates in memory; the sheared coordinates need the vertices in the
 // ray's permuted axis order, which is read straight from memory by index (selecting among
-// registers after wide loads of the record was measured 10 % slower for the whole kernel).
+// registers after wide loads of the record was measured 10 % slower for the whole kernel,
+// and a scalar-cache path for waves that share triangle and permutation 3 % slower).
 RT_DEV bool rayIntersectsTriangle(const Ray& ray, const RayPrep& p, const double* tp, double* bary, Vec* position,
                                   double* distance)
 {
@@ -556,6 +557,16 @@ RT_DEV void quadUpdate(double* q)
     q[15] = iv.x; q[16] = iv.y; q[17] = iv.z;
 }
 
+// The scene's arrays are never written while a kernel runs.  Reading an element that every lane
+// of the wave wants (volume v of the loop over volumes, the first light, ...) through the
+// constant address space lets the compiler fetch it once per wave through the scalar cache
+// instead of once per lane through the vector path.
+template <class T>
+RT_DEV const __attribute__((address_space(4))) T* uniformRead(const T* p)
+{
+    return reinterpret_cast<const __attribute__((address_space(4))) T*>(reinterpret_cast<unsigned long long>(p));
+}
+
 // ------------------------------------------------------------------ scene cast
 // Per-lane traversal stack in LDS: entry k of lane t lives at base[k * stride] so that
 // the 64 lanes of a wave always touch 64 different banks.  An entry packs the node
@@ -613,19 +624,19 @@ RT_DEV bool slabTestChild(const Ray& ray, const RayPrep& p, const float* box, do
 // without another fetch.  Triangle tests are deferred until every lane of the wave has
 // either reached a leaf or run out of nodes, so that the lanes test triangles together
 // instead of one lane at a time.
-RT_DEV bool castMesh(const SceneView& s, const Volume& vol, const Ray& ray, const RayPrep& prep,
-                     const TraversalStack& stack, double bound, double* bary, Vec* position, double* distance,
-                     int32_t* triSlot)
+RT_DEV bool castMesh(const SceneView& s, int32_t nodeBase, int32_t nodeCount, int64_t triBase, double extent,
+                     const Ray& ray, const RayPrep& prep, const TraversalStack& stack, double bound, double* bary,
+                     Vec* position, double* distance, int32_t* triSlot)
 {
-    if (vol.nodeCount <= 0)
+    if (nodeCount <= 0)
     {
         return false;
     }
     RT_DIAG_TRIP(0);  // mesh casts
-    const Node* nodes = s.nodes + vol.nodeBase;
-    const double* triRec = s.triRec + 16 * vol.triBase;
+    const Node* nodes = s.nodes + nodeBase;
+    const double* triRec = s.triRec + 16 * triBase;
     const double dlen = magnitude(ray.d);
-    const double slack = 1e-11 * (vol.extent + dabs(ray.o.x) + dabs(ray.o.y) + dabs(ray.o.z));
+    const double slack = 1e-11 * (extent + dabs(ray.o.x) + dabs(ray.o.y) + dabs(ray.o.z));
     bool found = false;
     double best = kMaxDouble;
     int32_t bestSlot = 0x7fffffff, bestRank = 0x7fffffff;
@@ -644,14 +655,35 @@ RT_DEV bool castMesh(const SceneView& s, const Volume& vol, const Ray& ray, cons
             RT_DIAG_TRIP(4);  // node steps
             if (cur >= 0)
             {
-                const Node& node = nodes[cur];
-                const float4 q0 = reinterpret_cast<const float4*>(&node)[0];
-                const float4 q1 = reinterpret_cast<const float4*>(&node)[1];
-                const float4 q2 = reinterpret_cast<const float4*>(&node)[2];
-                const int4 links = reinterpret_cast<const int4*>(&node)[3];
-                const float leftBox[6] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y};
-                const float rightBox[6] = {q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
-                const int32_t left = links.x, right = links.y;
+                // Photons that left the light together mostly stand on the same node: then the
+                // node comes through the scalar cache, once for the wave.
+                float leftBox[6], rightBox[6];
+                int32_t left, right;
+                const int32_t shared = __builtin_amdgcn_readfirstlane(cur);
+                if (__ballot(cur != shared) == 0)
+                {
+                    const auto node = uniformRead(nodes + shared);
+#pragma unroll
+                    for (int k = 0; k < 6; ++k)
+                    {
+                        leftBox[k] = node->leftBox[k];
+                        rightBox[k] = node->rightBox[k];
+                    }
+                    left = node->left;
+                    right = node->right;
+                }
+                else
+                {
+                    const Node& node = nodes[cur];
+                    const float4 q0 = reinterpret_cast<const float4*>(&node)[0];
+                    const float4 q1 = reinterpret_cast<const float4*>(&node)[1];
+                    const float4 q2 = reinterpret_cast<const float4*>(&node)[2];
+                    const int4 links = reinterpret_cast<const int4*>(&node)[3];
+                    leftBox[0] = q0.x; leftBox[1] = q0.y; leftBox[2] = q0.z; leftBox[3] = q0.w; leftBox[4] = q1.x; leftBox[5] = q1.y;
+                    rightBox[0] = q1.z; rightBox[1] = q1.w; rightBox[2] = q2.x; rightBox[3] = q2.y; rightBox[4] = q2.z; rightBox[5] = q2.w;
+                    left = links.x;
+                    right = links.y;
+                }
                 double el, er;
                 bool okl = slabTestChild(ray, prep, leftBox, &el);
                 bool okr = slabTestChild(ray, prep, rightBox, &er);
@@ -879,12 +911,13 @@ RT_DEV bool castScene(const SceneView& s, const Ray& ray, float time, double sel
     int32_t bestVolume = -1, bestTri = -1;
     for (int32_t v = 0; v < s.volumeCount; ++v)
     {
-        const Volume& vol = s.volumes[v];
-        Vec vpos = mk(vol.pos[0], vol.pos[1], vol.pos[2]);
-        Quat inv = vol.inv;
-        if (Animated && vol.animation >= 0)
+        const auto vol = uniformRead(s.volumes + v);  // v is the same in every lane
+        const int32_t type = vol->type;
+        Vec vpos = mk(vol->pos[0], vol->pos[1], vol->pos[2]);
+        Quat inv = Quat{vol->inv.x, vol->inv.y, vol->inv.z, vol->inv.w};
+        if (Animated && vol->animation >= 0)
         {
-            const Pose pose = poseAt(s, vol.animation, time);
+            const Pose pose = poseAt(s, vol->animation, time);
             vpos = pose.position;
             inv = quatInverse(pose.rotation);
         }
@@ -895,18 +928,20 @@ RT_DEV bool castScene(const SceneView& s, const Ray& ray, float time, double sel
         double dist;
         bool found = false;
         int32_t tri = -1;
-        if (vol.type == RT_VOLUME_MESH)
+        if (type == RT_VOLUME_MESH)
         {
             const RayPrep prep = prepareRay(local);
             double bary[3];
             int32_t slot = 0;
-            found = castMesh(s, vol, local, prep, stack, minDistance, bary, &pos, &dist, &slot);
+            const int64_t triBase = vol->triBase;
+            found = castMesh(s, vol->nodeBase, vol->nodeCount, triBase, vol->extent, local, prep, stack, minDistance, bary,
+                             &pos, &dist, &slot);
             if (found && dist < minDistance && dist > selfHit)
             {
                 if (needSurface)
                 {
-                    nrm = triangleNormal(s.triNrm + 9 * (vol.triBase + slot), bary);
-                    tri = s.triId[vol.triBase + slot];
+                    nrm = triangleNormal(s.triNrm + 9 * (triBase + slot), bary);
+                    tri = s.triId[triBase + slot];
                 }
             }
             else
@@ -914,19 +949,25 @@ RT_DEV bool castScene(const SceneView& s, const Ray& ray, float time, double sel
                 found = false;
             }
         }
-        else if (vol.type == RT_VOLUME_SPHERE)
+        else if (type == RT_VOLUME_SPHERE)
         {
-            found = rayIntersectsSphere(local, mk(vol.param[0], vol.param[1], vol.param[2]), vol.param[3], &pos, &nrm,
+            found = rayIntersectsSphere(local, mk(vol->param[0], vol->param[1], vol->param[2]), vol->param[3], &pos, &nrm,
                                         &dist);
         }
-        else if (vol.type == RT_VOLUME_QUAD)
+        else if (type == RT_VOLUME_QUAD)
         {
+            double quad[18];
+#pragma unroll
+            for (int k = 0; k < 18; ++k)
+            {
+                quad[k] = vol->param[k];
+            }
             Vec uv;
-            found = rayIntersectsQuad(local, vol.param, &pos, &nrm, &dist, &uv);
+            found = rayIntersectsQuad(local, quad, &pos, &nrm, &dist, &uv);
         }
         else
         {
-            found = rayIntersectsPlane(local, mk(vol.param[0], vol.param[1], vol.param[2]), vol.param[3], &pos, &nrm,
+            found = rayIntersectsPlane(local, mk(vol->param[0], vol->param[1], vol->param[2]), vol->param[3], &pos, &nrm,
                                        &dist);
         }
         if (found && dist < minDistance && dist > selfHit)

@@ -91,6 +91,9 @@ constexpr int kTileBits = 20;       // ids per tile = 2^kTileBits
 constexpr int kTileAxisBits = 7;    // a tile is bucketed into a 128 x 128 grid
 void launchEmissionTiles(const TraceArgs& args, uint32_t* order, hipStream_t stream);
 void launchTrace(const TraceArgs& args, int blocks, int threads, hipStream_t stream);
+// Orders every window of 4096 positions of the pass (args.emissionOrder, or the identity when
+// null) by a fine emission grid and writes the ids to `ordered` (a different buffer).
+void launchChunkSort(const TraceArgs& args, uint32_t* ordered, hipStream_t stream);
 void launchCastRays(const SceneView& scene, int64_t n, const double* rays, double selfHit, double* outF64,
                     int32_t* outI32, hipStream_t stream);
 void launchEmit(const SceneView& scene, int32_t light, int64_t n, const double* draws5, uint64_t totalPhotons,

@@ -29,7 +29,8 @@ constexpr unsigned long long kChunk = 4096;  // most photon ids a wave claims pe
 // the LDS a wave needs for it: sorted ids (u16) + cell counters (u32).  Two blocks of four
 // waves must fit a CU's 160 KB of LDS next to their traversal stacks.
 constexpr int kSortAxis = 32, kSortCells = kSortAxis * kSortAxis;
-constexpr int kSortBytesPerWave = static_cast<int>(kChunk) * 2 + kSortCells * 4;
+constexpr int kSortBytesPerWave = static_cast<int>(kChunk) * 4 + kSortCells * 4;  // sorted ids, keys, cell counters
+constexpr int kChunkSortThreads = 256;
 constexpr double kSelfHitThreshold = 1e-4;   // reference src/Worker.cpp:36
 
 RT_DEV unsigned lanesBelow(unsigned long long mask)
@@ -359,44 +360,87 @@ RT_DEV uint32_t spreadBits5(uint32_t v)  // 5 bits -> every other bit
     return v;
 }
 
-// cell of photon `id` in the sort grid, in Morton order
+// A pass numbers its photons light by light: id = light * photonCount + (index - firstPhoton).
+// Most scenes have one light and most passes fit 32 bits; the 64-bit division is the last resort.
+RT_DEV void splitPhotonId(const TraceArgs& a, unsigned long long id, int* lightId, unsigned long long* photonIndex)
+{
+    if (id < a.photonCount)
+    {
+        *lightId = 0;
+        *photonIndex = a.firstPhoton + id;
+    }
+    else if (((id | a.photonCount) >> 32) == 0)
+    {
+        const uint32_t light = static_cast<uint32_t>(id) / static_cast<uint32_t>(a.photonCount);
+        *lightId = static_cast<int>(light);
+        *photonIndex = a.firstPhoton + (static_cast<uint32_t>(id) - light * static_cast<uint32_t>(a.photonCount));
+    }
+    else
+    {
+        *lightId = static_cast<int>(id / a.photonCount);
+        *photonIndex = a.firstPhoton + id % a.photonCount;
+    }
+}
+
 RT_DEV unsigned long long photonAt(const TraceArgs& a, unsigned long long position)
 {
     return a.emissionOrder ? static_cast<unsigned long long>(a.emissionOrder[position]) : position;
 }
 
-RT_DEV uint32_t sortKey(const TraceArgs& a, unsigned long long position, Rng& rng)
+// The two uniform draws that steer photon `id`'s initial direction.
+RT_DEV void emissionDraws(const TraceArgs& a, unsigned long long id, Rng& rng, double* u0, double* u1)
 {
-    const unsigned long long id = photonAt(a, position);
-    const int lightId = static_cast<int>(id / a.photonCount);
-    const unsigned long long photonIndex = a.firstPhoton + id % a.photonCount;
+    int lightId;
+    unsigned long long photonIndex;
+    splitPhotonId(a, id, &lightId, &photonIndex);
     rng.begin(static_cast<uint32_t>(lightId), photonIndex, RT_STAGE_EMIT);
-    double u0 = rng.value(), u1 = rng.value();
+    *u0 = rng.value();
+    *u1 = rng.value();
     if (a.scene.lights[lightId].type == RT_LIGHT_AREA)
     {
         // an area light draws its origin first; the direction comes from draws 3 and 4
-        u0 = rng.value();
-        u1 = rng.value();
+        *u0 = rng.value();
+        *u1 = rng.value();
     }
-    // after the tile sort a chunk is a run of kChunk / (tile ids per cell) neighbouring cells of
-    // the tile's grid, about a square of `side` cells: order it by a grid kSortAxis / side times
-    // as fine, whose cell numbers (taken modulo the kSortAxis x kSortAxis buckets) are distinct
-    // across such a run
-    // (sized for a full chunk; a smaller chunk of a small pass is merely sorted finer than needed)
-    constexpr int kCellsPerChunk = static_cast<int>(kChunk >> (kTileBits - 2 * kTileAxisBits));
-    constexpr int kSide = kCellsPerChunk >= 256 ? 16 : (kCellsPerChunk >= 64 ? 8 : (kCellsPerChunk >= 16 ? 4 : 2));
-    const double scale =
-        a.emissionOrder ? static_cast<double>((kSortAxis / kSide) << kTileAxisBits) : 1.0 * kSortAxis;
+}
+
+// Key of the window sort.  After the tile sort a window is a run of kChunk / (tile ids per cell)
+// neighbouring cells of the tile's grid, about a square of `side` cells: it is ordered by a grid
+// kSortAxis / side times as fine, whose cell numbers (taken modulo the kSortAxis x kSortAxis
+// buckets) are distinct across such a run.  Without a tile sort the grid spans the whole square.
+constexpr int kCellsPerChunk = static_cast<int>(kChunk >> (kTileBits - 2 * kTileAxisBits));
+constexpr int kSide = kCellsPerChunk >= 256 ? 16 : (kCellsPerChunk >= 64 ? 8 : (kCellsPerChunk >= 16 ? 4 : 2));
+constexpr int kFineAxis = (kSortAxis / kSide) << kTileAxisBits;
+
+RT_DEV uint32_t windowKey(double u0, double u1, bool tileSorted)
+{
+    const double scale = tileSorted ? static_cast<double>(kFineAxis) : 1.0 * kSortAxis;
     const uint32_t cx = static_cast<uint32_t>(u0 * scale) & (kSortAxis - 1);
     const uint32_t cy = static_cast<uint32_t>(u1 * scale) & (kSortAxis - 1);
     return spreadBits5(cx) | (spreadBits5(cy) << 1);
 }
 
-RT_DEV void sortChunk(const TraceArgs& a, unsigned long long chunkBase, uint32_t count, unsigned char* area, Rng& rng)
+// One wave orders one window of kChunk positions: counting sort in LDS (keys kept in LDS so
+// that every id's draws are computed once), then the window's ids are written out in order.
+__global__ __launch_bounds__(kChunkSortThreads) void chunkSortKernel(const TraceArgs a, uint32_t* ordered)
 {
+    extern __shared__ unsigned char rtSortArea[];
     const int lane = threadIdx.x & 63;
+    const unsigned long long window = static_cast<unsigned long long>(blockIdx.x) * (kChunkSortThreads / 64) + (threadIdx.x >> 6);
+    const unsigned long long chunkBase = window * kChunk;
+    if (chunkBase >= a.totalWork)
+    {
+        return;
+    }
+    const uint32_t count = static_cast<uint32_t>(a.totalWork - chunkBase < kChunk ? a.totalWork - chunkBase : kChunk);
+    unsigned char* area = rtSortArea + static_cast<size_t>(threadIdx.x >> 6) * kSortBytesPerWave;
     unsigned short* sorted = reinterpret_cast<unsigned short*>(area);
-    uint32_t* cells = reinterpret_cast<uint32_t*>(sorted + kChunk);
+    unsigned short* keys = sorted + kChunk;
+    uint32_t* cells = reinterpret_cast<uint32_t*>(keys + kChunk);
+    Rng rng;
+    rng.tape = nullptr;
+    rng.next = 0;
+    rng.seed = a.scene.seed;
     for (int c = lane; c < kSortCells; c += 64)
     {
         cells[c] = 0;
@@ -405,7 +449,11 @@ RT_DEV void sortChunk(const TraceArgs& a, unsigned long long chunkBase, uint32_t
     __builtin_amdgcn_wave_barrier();
     for (uint32_t j = lane; j < count; j += 64)
     {
-        atomicAdd(&cells[sortKey(a, chunkBase + j, rng)], 1u);
+        double u0, u1;
+        emissionDraws(a, photonAt(a, chunkBase + j), rng, &u0, &u1);
+        const uint32_t key = windowKey(u0, u1, a.emissionOrder != nullptr);
+        keys[j] = static_cast<unsigned short>(key);
+        atomicAdd(&cells[key], 1u);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -434,14 +482,17 @@ RT_DEV void sortChunk(const TraceArgs& a, unsigned long long chunkBase, uint32_t
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    // the keys are recomputed rather than kept: two draws cost less than the LDS they would take
     for (uint32_t j = lane; j < count; j += 64)
     {
-        const uint32_t at = atomicAdd(&cells[sortKey(a, chunkBase + j, rng)], 1u);
+        const uint32_t at = atomicAdd(&cells[keys[j]], 1u);
         sorted[at] = static_cast<unsigned short>(j);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    for (uint32_t j = lane; j < count; j += 64)
+    {
+        ordered[chunkBase + j] = static_cast<uint32_t>(photonAt(a, chunkBase + sorted[j]));
+    }
 }
 
 // Sink selects the deposit path and Record the per-photon path dump at compile time, so
@@ -454,11 +505,7 @@ __global__ __launch_bounds__(kTraceThreads) void traceKernel(const TraceArgs a)
     RT_DIAG_WAVE_BEGIN;
     RT_DIAG_TIC(kernelStart);
 
-    // this wave's chunk of photon ids, in emission order (LDS)
-    extern __shared__ unsigned long long rtTraversalStack[];
-    unsigned char* sortArea = reinterpret_cast<unsigned char*>(rtTraversalStack + static_cast<size_t>(s.stackDepth) * kTraceThreads) +
-                              static_cast<size_t>(threadIdx.x >> 6) * kSortBytesPerWave;
-    const unsigned short* sortedIds = reinterpret_cast<const unsigned short*>(sortArea);
+    // this wave's run of positions in the pass's emission-ordered id list
     unsigned long long chunkBase = 0;     // wave-uniform
     uint32_t chunkNext = 0, chunkCount = 0;
     bool exhausted = false;               // the global id range is used up (wave-uniform)
@@ -507,16 +554,12 @@ __global__ __launch_bounds__(kTraceThreads) void traceKernel(const TraceArgs a)
                                  ? static_cast<uint32_t>(a.totalWork - chunkBase < a.chunk ? a.totalWork - chunkBase : a.chunk)
                                  : 0u;
                 exhausted = chunkCount == 0;
-                if (chunkCount > 0)
-                {
-                    sortChunk(a, chunkBase, chunkCount, sortArea, rng);
-                }
             }
             const uint32_t rank = lanesBelow(needMask);
             const uint32_t avail = chunkCount - chunkNext;
             const uint32_t n = static_cast<uint32_t>(__builtin_popcountll(needMask));
             const bool served = need && rank < avail;
-            const unsigned long long id = served ? photonAt(a, chunkBase + sortedIds[chunkNext + rank]) : a.totalWork;
+            const unsigned long long id = served ? photonAt(a, chunkBase + chunkNext + rank) : a.totalWork;
             chunkNext += n < avail ? n : avail;
             if (need && !served && exhausted)
             {
@@ -525,8 +568,7 @@ __global__ __launch_bounds__(kTraceThreads) void traceKernel(const TraceArgs a)
             if (served)
             {
                 {
-                    lightId = static_cast<int>(id / a.photonCount);
-                    photonIndex = a.firstPhoton + id % a.photonCount;
+                    splitPhotonId(a, id, &lightId, &photonIndex);
                     const Light& light = s.lights[lightId];
                     rng.begin(static_cast<uint32_t>(lightId), photonIndex, RT_STAGE_EMIT);
                     ray = emitRay(light, rng);
@@ -1204,15 +1246,8 @@ RT_DEV uint32_t spreadBits8(uint32_t v)
 
 RT_DEV uint32_t emissionCell(const TraceArgs& a, unsigned long long id, Rng& rng)
 {
-    const int lightId = static_cast<int>(id / a.photonCount);
-    const unsigned long long photonIndex = a.firstPhoton + id % a.photonCount;
-    rng.begin(static_cast<uint32_t>(lightId), photonIndex, RT_STAGE_EMIT);
-    double u0 = rng.value(), u1 = rng.value();
-    if (a.scene.lights[lightId].type == RT_LIGHT_AREA)
-    {
-        u0 = rng.value();
-        u1 = rng.value();
-    }
+    double u0, u1;
+    emissionDraws(a, id, rng, &u0, &u1);
     const uint32_t axis = 1u << kTileAxisBits;
     const uint32_t cx = static_cast<uint32_t>(u0 * axis) & (axis - 1);
     const uint32_t cy = static_cast<uint32_t>(u1 * axis) & (axis - 1);
@@ -1274,6 +1309,8 @@ __global__ __launch_bounds__(kTileThreads) void emissionTileKernel(const TraceAr
         running += c;
     }
     __syncthreads();
+    // the cells are recomputed rather than kept: keeping them (and handing the window sort its
+    // keys) was measured slower — the scattered 2- and 4-byte writes cost more than the draws
     for (unsigned long long id = tileBase + threadIdx.x; id < tileEnd; id += kTileThreads)
     {
         const uint32_t at = atomicAdd(&cells[emissionCell(a, id, rng)], 1u);
@@ -1487,10 +1524,18 @@ TraceKernel traceVariant(const TraceArgs& args)
 
 size_t traceLdsBytes(const SceneView& scene)
 {
-    return stackBytes(scene, kTraceThreads) + (kTraceThreads / 64) * kSortBytesPerWave;
+    return stackBytes(scene, kTraceThreads);
 }
 
 }  // namespace
+
+void launchChunkSort(const TraceArgs& args, uint32_t* ordered, hipStream_t stream)
+{
+    const unsigned long long windows = (args.totalWork + kChunk - 1) / kChunk;
+    const unsigned long long perBlock = kChunkSortThreads / 64;
+    hipLaunchKernelGGL(chunkSortKernel, dim3(static_cast<unsigned>((windows + perBlock - 1) / perBlock)),
+                       dim3(kChunkSortThreads), perBlock * kSortBytesPerWave, stream, args, ordered);
+}
 
 void launchTrace(const TraceArgs& args, int blocks, int threads, hipStream_t stream)
 {
