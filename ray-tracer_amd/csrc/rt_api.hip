@@ -148,6 +148,8 @@ struct rt_tracer
     DeviceArray<double> probePoints;
     DeviceArray<unsigned long long> nearKey;
     DeviceArray<uint32_t> nearBits;
+    DeviceArray<rtd::PackedCell> packedCells;
+    DeviceArray<rtd::NearEntry> nearEntries;
     rtd::ProbeView probeView{};
     DeviceArray<float> storeRecords;
     uint64_t storeCapacity = 0;
@@ -712,8 +714,10 @@ bool buildProbesOnDevice(rt_tracer* tracer, const double* probes, uint64_t n, do
     tracer->slotCount.allocate(slots);
     tracer->probePoints.allocate(3 * n);
     tracer->slotCount.zero(stream);
+    tracer->packedCells.allocate(slots);
+    check(hipMemsetAsync(tracer->packedCells.ptr, 0xFF, slots * sizeof(rtd::PackedCell), stream), "hipMemsetAsync");
     rtd::launchProbeTable(keysOut.ptr, orderOut.ptr, points.ptr, n, tracer->slotKey.ptr, tracer->slotStart.ptr,
-                          tracer->slotCount.ptr, slots - 1, tracer->probePoints.ptr, stream);
+                          tracer->slotCount.ptr, tracer->packedCells.ptr, slots - 1, tracer->probePoints.ptr, stream);
 
     // the 27-neighbour filter: candidate keys, sorted, runs merged
     const uint64_t candidates = 27 * cellCount;
@@ -741,8 +745,10 @@ bool buildProbesOnDevice(rt_tracer* tracer, const double* probes, uint64_t n, do
     tracer->nearBits.allocate(nearSlots);
     check(hipMemsetAsync(tracer->nearKey.ptr, 0xFF, nearSlots * sizeof(unsigned long long), stream), "hipMemsetAsync");
     tracer->nearBits.zero(stream);
+    tracer->nearEntries.allocate(nearSlots);
+    check(hipMemsetAsync(tracer->nearEntries.ptr, 0xFF, nearSlots * sizeof(rtd::NearEntry), stream), "hipMemsetAsync");
     rtd::launchNeighbourTable(nearOut.ptr, bitsOut.ptr, candidates, tracer->nearKey.ptr, tracer->nearBits.ptr,
-                              nearSlots - 1, stream);
+                              tracer->nearEntries.ptr, nearSlots - 1, stream);
     check(hipGetLastError(), "probe grid build");
     check(hipStreamSynchronize(stream), "hipStreamSynchronize");
 
@@ -759,6 +765,8 @@ bool buildProbesOnDevice(rt_tracer* tracer, const double* probes, uint64_t n, do
     pv.nearKey = tracer->nearKey.ptr;
     pv.nearBits = tracer->nearBits.ptr;
     pv.nearMask = nearSlots - 1;
+    pv.packedCells = tracer->packedCells.ptr;
+    pv.nearEntries = tracer->nearEntries.ptr;
     return true;
 }
 
@@ -1188,6 +1196,8 @@ int32_t rt_set_probes(rt_tracer* tracer, const double* probes, uint64_t n, doubl
             pv.nearKey = tracer->nearKey.ptr;
             pv.nearBits = tracer->nearBits.ptr;
             pv.nearMask = nearSlots - 1;
+    pv.packedCells = tracer->packedCells.ptr;
+    pv.nearEntries = tracer->nearEntries.ptr;
         }
         tracer->probesSet = true;
     });

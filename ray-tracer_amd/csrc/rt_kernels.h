@@ -9,6 +9,9 @@ namespace rtd
 
 // Sink A: the probe keep-test grid (reference src/ProbeIndex.cpp) as an open-addressed
 // hash table in HBM, and the raw bounce store (reference src/BounceStore.cpp).
+struct PackedCell;
+struct NearEntry;
+
 struct ProbeView
 {
     const int64_t* slotKey;      // [slots][3] cell coordinates
@@ -26,6 +29,23 @@ struct ProbeView
     const unsigned long long* nearKey;  // [nearMask + 1] packed cell, kEmptyKey when free
     const uint32_t* nearBits;           // [nearMask + 1]
     uint64_t nearMask;
+    // The same two tables as single 16-byte entries (one load per lookup), filled together with
+    // the filter: packedCells[slot] mirrors slotKey / slotStart / slotCount, nearEntries[slot]
+    // mirrors nearKey / nearBits.  A free slot holds kEmptyKey.
+    const PackedCell* packedCells;
+    const NearEntry* nearEntries;
+};
+
+struct alignas(16) PackedCell
+{
+    unsigned long long key;  // packed cell coordinates
+    uint32_t start, count;   // its probes in `points`
+};
+
+struct alignas(16) NearEntry
+{
+    unsigned long long key;
+    uint32_t bits, reserved;
 };
 
 struct StoreView
@@ -152,12 +172,13 @@ size_t sortKeyPairs(void* scratch, size_t scratchBytes, const unsigned long long
                     const uint32_t* orderIn, uint32_t* orderOut, uint64_t n, hipStream_t stream);
 void launchCountRuns(const unsigned long long* sortedKeys, uint64_t n, unsigned long long* runs, hipStream_t stream);
 void launchProbeTable(const unsigned long long* sortedKeys, const uint32_t* sortedOrder, const double* points, uint64_t n,
-                      int64_t* slotKey, uint32_t* slotStart, uint32_t* slotCount, uint64_t slotMask,
-                      double* groupedPoints, hipStream_t stream);
+                      int64_t* slotKey, uint32_t* slotStart, uint32_t* slotCount, PackedCell* packedCells,
+                      uint64_t slotMask, double* groupedPoints, hipStream_t stream);
 void launchNeighbourKeys(const unsigned long long* sortedKeys, uint64_t n, unsigned long long* outKeys,
                          uint32_t* outBits, unsigned long long* cursor, hipStream_t stream);
 void launchNeighbourTable(const unsigned long long* sortedKeys, const uint32_t* sortedBits, uint64_t n,
-                          unsigned long long* nearKey, uint32_t* nearBits, uint64_t nearMask, hipStream_t stream);
+                          unsigned long long* nearKey, uint32_t* nearBits, NearEntry* nearEntries, uint64_t nearMask,
+                          hipStream_t stream);
 void launchProbeTest(const ProbeView& probes, int64_t n, const double* points, uint8_t* out, hipStream_t stream);
 
 }  // namespace rtd

@@ -98,6 +98,38 @@ RT_DEV bool probeCellHas(const ProbeView& pv, int64_t kx, int64_t ky, int64_t kz
     }
 }
 
+// probeCellHas through the packed table: one 16-byte entry per probe of the slot sequence.
+RT_DEV bool packedCellHas(const ProbeView& pv, int64_t kx, int64_t ky, int64_t kz, const Vec& p, double r2)
+{
+    const unsigned long long key = (static_cast<unsigned long long>(kx + kPackLimit) << 42) |
+                                   (static_cast<unsigned long long>(ky + kPackLimit) << 21) |
+                                   static_cast<unsigned long long>(kz + kPackLimit);
+    uint64_t slot = cellHash(kx, ky, kz) & pv.slotMask;
+    while (true)
+    {
+        const uint4 raw = *reinterpret_cast<const uint4*>(pv.packedCells + slot);
+        const unsigned long long seen = (static_cast<unsigned long long>(raw.y) << 32) | raw.x;
+        if (seen == key)
+        {
+            const double* pt = pv.points + 3ull * raw.z;
+            for (uint32_t i = 0; i < raw.w; ++i)
+            {
+                const double ddx = pt[3 * i] - p.x, ddy = pt[3 * i + 1] - p.y, ddz = pt[3 * i + 2] - p.z;
+                if (ddx * ddx + ddy * ddy + ddz * ddz <= r2)
+                {
+                    return true;
+                }
+            }
+            return false;
+        }
+        if (seen == kEmptyKey)
+        {
+            return false;
+        }
+        slot = (slot + 1) & pv.slotMask;
+    }
+}
+
 // ProbeIndex::anyWithin, reference src/ProbeIndex.cpp:27-68.  The result is a pure
 // "exists", so the scan order is free; the squared-distance test is the reference's
 // expression.  With the neighbourhood filter one lookup tells which of the 27 cells
@@ -129,10 +161,11 @@ RT_DEV bool anyProbeWithin(const ProbeView& pv, const Vec& p)
         uint32_t bits = 0;
         while (true)
         {
-            const unsigned long long seen = pv.nearKey[slot];
+            const uint4 raw = *reinterpret_cast<const uint4*>(pv.nearEntries + slot);
+            const unsigned long long seen = (static_cast<unsigned long long>(raw.y) << 32) | raw.x;
             if (seen == key)
             {
-                bits = pv.nearBits[slot];
+                bits = raw.z;
                 break;
             }
             if (seen == kEmptyKey)
@@ -146,7 +179,7 @@ RT_DEV bool anyProbeWithin(const ProbeView& pv, const Vec& p)
             const int b = __builtin_ctz(bits);
             bits &= bits - 1;
             const int dz = b / 9 - 1, dy = (b / 3) % 3 - 1, dx = b % 3 - 1;
-            if (probeCellHas(pv, cx + dx, cy + dy, cz + dz, p, r2))
+            if (packedCellHas(pv, cx + dx, cy + dy, cz + dz, p, r2))
             {
                 return true;
             }
@@ -193,19 +226,26 @@ RT_DEV void storeAppend(const StoreView& sv, bool keep, const Vec& position, con
         const unsigned long long slot = base + lanesBelow(mask);
         if (slot < sv.capacity)
         {
+            // 52-byte records are only 4-byte aligned; the hardware takes unaligned 16-byte stores,
+            // so a record is three of them and one float instead of thirteen floats
+            typedef float UnalignedFloat4 __attribute__((ext_vector_type(4), aligned(4)));
             float* r = sv.records + 13ull * slot;
-            r[0] = static_cast<float>(position.x);
-            r[1] = static_cast<float>(position.y);
-            r[2] = static_cast<float>(position.z);
-            r[3] = static_cast<float>(incoming.x);
-            r[4] = static_cast<float>(incoming.y);
-            r[5] = static_cast<float>(incoming.z);
-            r[6] = static_cast<float>(normal.x);
-            r[7] = static_cast<float>(normal.y);
-            r[8] = static_cast<float>(normal.z);
-            r[9] = time;
-            r[10] = power.r;
-            r[11] = power.g;
+            UnalignedFloat4 q0, q1, q2;
+            q0.x = static_cast<float>(position.x);
+            q0.y = static_cast<float>(position.y);
+            q0.z = static_cast<float>(position.z);
+            q0.w = static_cast<float>(incoming.x);
+            q1.x = static_cast<float>(incoming.y);
+            q1.y = static_cast<float>(incoming.z);
+            q1.z = static_cast<float>(normal.x);
+            q1.w = static_cast<float>(normal.y);
+            q2.x = static_cast<float>(normal.z);
+            q2.y = time;
+            q2.z = power.r;
+            q2.w = power.g;
+            *reinterpret_cast<UnalignedFloat4*>(r) = q0;
+            *reinterpret_cast<UnalignedFloat4*>(r + 4) = q1;
+            *reinterpret_cast<UnalignedFloat4*>(r + 8) = q2;
             r[12] = power.b;
         }
     }
@@ -1362,8 +1402,8 @@ __global__ void countRunsKernel(const unsigned long long* keys, uint64_t n, unsi
 // every probe is copied to its place in cell order; the first probe of every cell enters the
 // cell into the table (a slot is claimed through its count, 0 = free)
 __global__ void probeTableKernel(const unsigned long long* keys, const uint32_t* order, const double* points, uint64_t n,
-                                 int64_t* slotKey, uint32_t* slotStart, uint32_t* slotCount, uint64_t slotMask,
-                                 double* grouped)
+                                 int64_t* slotKey, uint32_t* slotStart, uint32_t* slotCount, PackedCell* packedCells,
+                                 uint64_t slotMask, double* grouped)
 {
     const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -1393,6 +1433,7 @@ __global__ void probeTableKernel(const unsigned long long* keys, const uint32_t*
     slotKey[3 * slot + 1] = y;
     slotKey[3 * slot + 2] = z;
     slotStart[slot] = static_cast<uint32_t>(i);
+    packedCells[slot] = PackedCell{key, static_cast<uint32_t>(i), count};
 }
 
 // for every occupied cell, the 27 cells around it, each with the bit that says "my neighbour
@@ -1430,7 +1471,8 @@ __global__ void neighbourKeysKernel(const unsigned long long* keys, uint64_t n, 
 
 // sorted neighbour keys: the first of every run ORs the run's bits and enters the table
 __global__ void neighbourTableKernel(const unsigned long long* keys, const uint32_t* bits, uint64_t n,
-                                     unsigned long long* nearKey, uint32_t* nearBits, uint64_t nearMask)
+                                     unsigned long long* nearKey, uint32_t* nearBits, NearEntry* nearEntries,
+                                     uint64_t nearMask)
 {
     const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -1450,6 +1492,7 @@ __global__ void neighbourTableKernel(const unsigned long long* keys, const uint3
         slot = (slot + 1) & nearMask;
     }
     nearBits[slot] = all;
+    nearEntries[slot] = NearEntry{key, all, 0u};
 }
 
 int gridFor(int64_t n) { return static_cast<int>((n + 255) / 256); }
@@ -1647,12 +1690,12 @@ void launchCountRuns(const unsigned long long* sortedKeys, uint64_t n, unsigned 
 }
 
 void launchProbeTable(const unsigned long long* sortedKeys, const uint32_t* sortedOrder, const double* points, uint64_t n,
-                      int64_t* slotKey, uint32_t* slotStart, uint32_t* slotCount, uint64_t slotMask,
-                      double* groupedPoints, hipStream_t stream)
+                      int64_t* slotKey, uint32_t* slotStart, uint32_t* slotCount, PackedCell* packedCells,
+                      uint64_t slotMask, double* groupedPoints, hipStream_t stream)
 {
     if (n == 0) return;
     hipLaunchKernelGGL(probeTableKernel, dim3(gridFor(static_cast<int64_t>(n))), dim3(256), 0, stream, sortedKeys, sortedOrder,
-                       points, n, slotKey, slotStart, slotCount, slotMask, groupedPoints);
+                       points, n, slotKey, slotStart, slotCount, packedCells, slotMask, groupedPoints);
 }
 
 void launchNeighbourKeys(const unsigned long long* sortedKeys, uint64_t n, unsigned long long* outKeys,
@@ -1664,11 +1707,12 @@ void launchNeighbourKeys(const unsigned long long* sortedKeys, uint64_t n, unsig
 }
 
 void launchNeighbourTable(const unsigned long long* sortedKeys, const uint32_t* sortedBits, uint64_t n,
-                          unsigned long long* nearKey, uint32_t* nearBits, uint64_t nearMask, hipStream_t stream)
+                          unsigned long long* nearKey, uint32_t* nearBits, NearEntry* nearEntries, uint64_t nearMask,
+                          hipStream_t stream)
 {
     if (n == 0) return;
     hipLaunchKernelGGL(neighbourTableKernel, dim3(gridFor(static_cast<int64_t>(n))), dim3(256), 0, stream, sortedKeys, sortedBits,
-                       n, nearKey, nearBits, nearMask);
+                       n, nearKey, nearBits, nearEntries, nearMask);
 }
 
 void launchProbeTest(const ProbeView& probes, int64_t n, const double* points, uint8_t* out, hipStream_t stream)
