@@ -8,6 +8,7 @@
 #include "rt_kernels.h"
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -256,6 +257,7 @@ void buildScene(rt_tracer* t, const rt_scene* scene)
         int32_t nodeBase, nodeCount;
         int64_t triBase;
         double extent;
+        double lo[3], hi[3];  // object-space bounds
     };
     std::vector<MeshSpan> spans;
     int maxDepth = 1;
@@ -292,6 +294,18 @@ void buildScene(rt_tracer* t, const rt_scene* scene)
         span.nodeCount = static_cast<int32_t>(wide.nodes.size());
         span.triBase = static_cast<int64_t>(triId.size());
         span.extent = extent;
+        for (int k = 0; k < 3; ++k)
+        {
+            span.lo[k] = span.hi[k] = mesh.triangle_count > 0 ? pos[k] : 0.0;
+        }
+        for (int64_t i = 0; i < 3 * mesh.triangle_count; ++i)
+        {
+            for (int k = 0; k < 3; ++k)
+            {
+                span.lo[k] = std::min(span.lo[k], pos[3 * i + k]);
+                span.hi[k] = std::max(span.hi[k], pos[3 * i + k]);
+            }
+        }
         for (const rtbvh::WideNode& wn : wide.nodes)
         {
             rtd::Node n;
@@ -364,6 +378,66 @@ void buildScene(rt_tracer* t, const rt_scene* scene)
         {
             require(rv.type == RT_VOLUME_SPHERE || rv.type == RT_VOLUME_QUAD || rv.type == RT_VOLUME_PLANE,
                     "unknown volume type");
+        }
+        // world-space box of a static volume: its object-space corners through the volume's
+        // transform, grown by a millionth of the scene's scale (the transforms round at 1e-16 of it)
+        // and rounded outward to single precision
+        std::vector<std::array<double, 3>> corners;
+        if (v.animation < 0)
+        {
+            if (rv.type == RT_VOLUME_MESH && scene->meshes[rv.mesh].triangle_count > 0)
+            {
+                const MeshSpan& span = spans[rv.mesh];
+                for (int c = 0; c < 8; ++c)
+                {
+                    corners.push_back({(c & 1) ? span.hi[0] : span.lo[0], (c & 2) ? span.hi[1] : span.lo[1],
+                                       (c & 4) ? span.hi[2] : span.lo[2]});
+                }
+            }
+            else if (rv.type == RT_VOLUME_SPHERE)
+            {
+                corners.push_back({rv.param[0], rv.param[1], rv.param[2]});  // the centre; the radius is added below
+            }
+            else if (rv.type == RT_VOLUME_QUAD)
+            {
+                for (int c = 0; c < 4; ++c)
+                {
+                    std::array<double, 3> corner{rv.param[0], rv.param[1], rv.param[2]};
+                    for (int k = 0; k < 3; ++k)
+                    {
+                        corner[k] += ((c & 1) ? rv.param[3 + k] : 0.0) + ((c & 2) ? rv.param[6 + k] : 0.0);
+                    }
+                    corners.push_back(corner);
+                }
+            }
+        }
+        if (!corners.empty())
+        {
+            double lo[3], hi[3];
+            bool finite = true;
+            for (size_t c = 0; c < corners.size(); ++c)
+            {
+                double world[3];
+                hostRotate(rv.rotation, corners[c].data(), world);
+                for (int k = 0; k < 3; ++k)
+                {
+                    world[k] += rv.position[k];
+                    finite = finite && std::isfinite(world[k]);
+                    lo[k] = c == 0 ? world[k] : std::min(lo[k], world[k]);
+                    hi[k] = c == 0 ? world[k] : std::max(hi[k], world[k]);
+                }
+            }
+            const double grow =
+                1e-6 * sceneScale + (rv.type == RT_VOLUME_SPHERE ? std::fabs(rv.param[3]) * (1.0 + 1e-6) : 0.0);
+            if (finite)
+            {
+                v.hasWorldBox = 1;
+                for (int k = 0; k < 3; ++k)
+                {
+                    v.worldBox[k] = std::nextafter(static_cast<float>(lo[k] - grow), -std::numeric_limits<float>::infinity());
+                    v.worldBox[3 + k] = std::nextafter(static_cast<float>(hi[k] + grow), std::numeric_limits<float>::infinity());
+                }
+            }
         }
         volumes.push_back(v);
     }

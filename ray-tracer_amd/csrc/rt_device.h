@@ -161,7 +161,12 @@ struct Volume
 {
     int32_t type, material, nodeBase, nodeCount;
     int64_t triBase;  // first triangle of the mesh in the page-ordered arrays
-    int32_t animation, pad;  // index into SceneView::animations, or -1 for a static volume
+    int32_t animation;       // index into SceneView::animations, or -1 for a static volume
+    int32_t hasWorldBox;     // worldBox is set (static mesh, sphere or quad)
+    // Box around the volume in WORLD space, grown far beyond the rounding of the transforms: a ray
+    // that misses it, or enters it beyond the nearest hit so far, cannot hit the volume, and
+    // the cast skips it without transforming the ray.
+    float worldBox[6];
     double extent;           // largest |coordinate| of the mesh (scale of the pruning slack)
     double pos[3];
     Quat rot, inv;    // rotation and Quaternion::inverse() of it (src/Quaternion.cpp:49-52)
@@ -909,10 +914,38 @@ RT_DEV bool castScene(const SceneView& s, const Ray& ray, float time, double sel
     bool valid = false;
     Vec bestPos = mk(0, 0, 0), bestNrm = mk(0, 0, 0);
     int32_t bestVolume = -1, bestTri = -1;
+    // reciprocal direction of the world ray for the per-volume box test (+inf on an axis the ray
+    // runs parallel to: the slab arithmetic then reduces to containment, as in slabTest)
+    double worldOod[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+    {
+        const double d = axisOf(ray.d, i);
+        worldOod[i] = dabs(d) < kEps ? __builtin_inf() : 1.0 / d;
+    }
+    const double worldLength = magnitude(ray.d);
     for (int32_t v = 0; v < s.volumeCount; ++v)
     {
         const auto vol = uniformRead(s.volumes + v);  // v is the same in every lane
         const int32_t type = vol->type;
+        if (vol->hasWorldBox)
+        {
+            double tmin = 0.0, tmax = kMaxDouble;
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+            {
+                const double origin = axisOf(ray.o, i);
+                const double t1 = (static_cast<double>(vol->worldBox[i]) - origin) * worldOod[i];
+                const double t2 = (static_cast<double>(vol->worldBox[3 + i]) - origin) * worldOod[i];
+                const bool reversed = worldOod[i] < 0.0;
+                tmin = __builtin_fmax(tmin, reversed ? t2 : t1);
+                tmax = __builtin_fmin(tmax, reversed ? t1 : t2);
+            }
+            if (tmin > tmax || tmin * worldLength > minDistance * (1.0 + 1e-9))
+            {
+                continue;
+            }
+        }
         Vec vpos = mk(vol->pos[0], vol->pos[1], vol->pos[2]);
         Quat inv = Quat{vol->inv.x, vol->inv.y, vol->inv.z, vol->inv.w};
         if (Animated && vol->animation >= 0)
