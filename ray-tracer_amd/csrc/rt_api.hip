@@ -166,7 +166,8 @@ struct rt_tracer
     DeviceArray<unsigned long long> scalars;
     DeviceArray<rtd::DeviceCounters> counters;
     // emission-order list of a pass's photon ids
-    DeviceArray<uint32_t> tileOrder, sortOrder;
+    DeviceArray<uint32_t> sortIds, sortOrder, sortKeysIn, sortKeysOut;
+    DeviceArray<unsigned char> sortScratch;
     // events around the stages of the last rt_trace: before the sort, after it, after the trace kernel
     hipEvent_t stageEvents[3] = {nullptr, nullptr, nullptr};
     bool timed = false;
@@ -1409,21 +1410,27 @@ int32_t rt_trace(rt_tracer* tracer, const rt_trace_params* params)
             if (e == nullptr) check(hipEventCreate(&e), "hipEventCreate");
         }
         check(hipEventRecord(tracer->stageEvents[0], tracer->stream), "hipEventRecord");
-        // Passes are traced in emission order (a schedule only; see emissionTileKernel): large ones
-        // are first sorted coarsely tile by tile, then every window of 4096 positions finely.
+        // Passes are traced in emission order (a schedule only; see emissionKeysKernel): every id is
+        // keyed by its emission cell and the (key, id) pairs are radix-sorted.
         args.emissionOrder = nullptr;
-        if (args.totalWork < (1ull << 32))
+        if (args.totalWork < (1ull << 31))
         {
-            if (tracer->sortOrder.count < args.totalWork) tracer->sortOrder.allocate(args.totalWork);
-            if (args.totalWork >= (1ull << 20))
+            const uint64_t n = args.totalWork;
+            if (tracer->sortOrder.count < n)
             {
-                if (tracer->tileOrder.count < args.totalWork) tracer->tileOrder.allocate(args.totalWork);
-                rtd::launchEmissionTiles(args, tracer->tileOrder.ptr, tracer->stream);
-                check(hipGetLastError(), "emission tile sort launch");
-                args.emissionOrder = tracer->tileOrder.ptr;
+                tracer->sortOrder.allocate(n);
+                tracer->sortIds.allocate(n);
+                tracer->sortKeysIn.allocate(n);
+                tracer->sortKeysOut.allocate(n);
             }
-            rtd::launchChunkSort(args, tracer->sortOrder.ptr, tracer->stream);
-            check(hipGetLastError(), "emission window sort launch");
+            rtd::launchEmissionKeys(args, tracer->sortKeysIn.ptr, tracer->sortIds.ptr, tracer->stream);
+            const int lights = static_cast<int>(tracer->lightCount);
+            const size_t bytes = rtd::sortEmissionPairs(nullptr, 0, tracer->sortKeysIn.ptr, tracer->sortKeysOut.ptr,
+                                                        tracer->sortIds.ptr, tracer->sortOrder.ptr, n, lights, tracer->stream);
+            if (tracer->sortScratch.count < bytes) tracer->sortScratch.allocate(bytes);
+            rtd::sortEmissionPairs(tracer->sortScratch.ptr, bytes, tracer->sortKeysIn.ptr, tracer->sortKeysOut.ptr,
+                                   tracer->sortIds.ptr, tracer->sortOrder.ptr, n, lights, tracer->stream);
+            check(hipGetLastError(), "emission sort");
             args.emissionOrder = tracer->sortOrder.ptr;
         }
         check(hipEventRecord(tracer->stageEvents[1], tracer->stream), "hipEventRecord");

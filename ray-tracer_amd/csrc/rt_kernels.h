@@ -106,14 +106,12 @@ struct TraceArgs
     int32_t sinkMode;
 };
 
-// Tile-wise emission-order sort of the photon ids of one pass (see emissionTileKernel).
-constexpr int kTileBits = 20;       // ids per tile = 2^kTileBits
-constexpr int kTileAxisBits = 7;    // a tile is bucketed into a 128 x 128 grid
-void launchEmissionTiles(const TraceArgs& args, uint32_t* order, hipStream_t stream);
 void launchTrace(const TraceArgs& args, int blocks, int threads, hipStream_t stream);
-// Orders every window of 4096 positions of the pass (args.emissionOrder, or the identity when
-// null) by a fine emission grid and writes the ids to `ordered` (a different buffer).
-void launchChunkSort(const TraceArgs& args, uint32_t* ordered, hipStream_t stream);
+// Whole-pass emission order: keys and ids of every photon of the pass, then a radix sort of the pairs
+// (returns the scratch bytes needed when scratch is null).
+void launchEmissionKeys(const TraceArgs& args, uint32_t* keys, uint32_t* ids, hipStream_t stream);
+size_t sortEmissionPairs(void* scratch, size_t scratchBytes, const uint32_t* keysIn, uint32_t* keysOut, const uint32_t* idsIn,
+                         uint32_t* idsOut, uint64_t n, int lightCount, hipStream_t stream);
 void launchCastRays(const SceneView& scene, int64_t n, const double* rays, double selfHit, double* outF64,
                     int32_t* outI32, hipStream_t stream);
 void launchEmit(const SceneView& scene, int32_t light, int64_t n, const double* draws5, uint64_t totalPhotons,

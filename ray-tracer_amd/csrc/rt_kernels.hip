@@ -24,13 +24,6 @@ namespace
 {
 
 constexpr int kTraceThreads = 256;
-constexpr unsigned long long kChunk = 4096;  // most photon ids a wave claims per atomic (TraceArgs::chunk)
-// Emission-order sort of a chunk (see sortChunk): a grid of kSortAxis x kSortAxis cells and
-// the LDS a wave needs for it: sorted ids (u16) + cell counters (u32).  Two blocks of four
-// waves must fit a CU's 160 KB of LDS next to their traversal stacks.
-constexpr int kSortAxis = 32, kSortCells = kSortAxis * kSortAxis;
-constexpr int kSortBytesPerWave = static_cast<int>(kChunk) * 4 + kSortCells * 4;  // sorted ids, keys, cell counters
-constexpr int kChunkSortThreads = 256;
 constexpr double kSelfHitThreshold = 1e-4;   // reference src/Worker.cpp:36
 
 RT_DEV unsigned lanesBelow(unsigned long long mask)
@@ -384,21 +377,10 @@ RT_DEV void splatToCamera(const TraceArgs& a, const Vec& incoming, const Color& 
     }
 }
 
-// A wave's chunk of photon ids is traced in EMISSION ORDER rather than id order: the ids
-// are bucketed by the cell of a grid over the two uniform draws
-// that steer the photon's initial direction (cells in Morton order), so that the 64
-// photons a wave holds at any time leave the light in nearly the same direction, walk
-// nearly the same nodes and finish their casts together.  A photon's path depends only
-// on its id (the counter-based draws), so the order changes nothing but the schedule.
-// `area` is this wave's sort scratch in LDS; on return sorted[0 .. count) holds the
-// chunk-relative ids.
-RT_DEV uint32_t spreadBits5(uint32_t v)  // 5 bits -> every other bit
-{
-    v = (v | (v << 4)) & 0x0F0Fu;
-    v = (v | (v << 2)) & 0x3333u;
-    v = (v | (v << 1)) & 0x5555u;
-    return v;
-}
+// A pass is traced in EMISSION ORDER rather than id order (TraceArgs::emissionOrder): the 64
+// photons a wave holds at any time leave the light in nearly the same direction, walk nearly
+// the same nodes and finish their casts together.  A photon's path depends only on its id
+// (the counter-based draws), so the order changes nothing but the schedule.
 
 // A pass numbers its photons light by light: id = light * photonCount + (index - firstPhoton).
 // Most scenes have one light and most passes fit 32 bits; the 64-bit division is the last resort.
@@ -444,95 +426,39 @@ RT_DEV void emissionDraws(const TraceArgs& a, unsigned long long id, Rng& rng, d
     }
 }
 
-// Key of the window sort.  After the tile sort a window is a run of kChunk / (tile ids per cell)
-// neighbouring cells of the tile's grid, about a square of `side` cells: it is ordered by a grid
-// kSortAxis / side times as fine, whose cell numbers (taken modulo the kSortAxis x kSortAxis
-// buckets) are distinct across such a run.  Without a tile sort the grid spans the whole square.
-constexpr int kCellsPerChunk = static_cast<int>(kChunk >> (kTileBits - 2 * kTileAxisBits));
-constexpr int kSide = kCellsPerChunk >= 256 ? 16 : (kCellsPerChunk >= 64 ? 8 : (kCellsPerChunk >= 16 ? 4 : 2));
-constexpr int kFineAxis = (kSortAxis / kSide) << kTileAxisBits;
+// Whole-pass emission order: every id gets the Morton number of its cell in a 4096 x 4096 grid
+// over the two steering draws (above it the light, so that lights do not interleave); a radix
+// sort of (key, id) then puts photons that leave a light in nearly the same direction next to
+// each other across the whole pass.
+constexpr int kGlobalAxisBits = 12;
 
-RT_DEV uint32_t windowKey(double u0, double u1, bool tileSorted)
+RT_DEV uint32_t spreadBits12(uint32_t v)
 {
-    const double scale = tileSorted ? static_cast<double>(kFineAxis) : 1.0 * kSortAxis;
-    const uint32_t cx = static_cast<uint32_t>(u0 * scale) & (kSortAxis - 1);
-    const uint32_t cy = static_cast<uint32_t>(u1 * scale) & (kSortAxis - 1);
-    return spreadBits5(cx) | (spreadBits5(cy) << 1);
+    v = (v | (v << 8)) & 0x00FF00FFu;
+    v = (v | (v << 4)) & 0x0F0F0F0Fu;
+    v = (v | (v << 2)) & 0x33333333u;
+    v = (v | (v << 1)) & 0x55555555u;
+    return v;
 }
 
-// One wave orders one window of kChunk positions: counting sort in LDS (keys kept in LDS so
-// that every id's draws are computed once), then the window's ids are written out in order.
-__global__ __launch_bounds__(kChunkSortThreads) void chunkSortKernel(const TraceArgs a, uint32_t* ordered)
+__global__ void emissionKeysKernel(const TraceArgs a, uint32_t* keys, uint32_t* ids)
 {
-    extern __shared__ unsigned char rtSortArea[];
-    const int lane = threadIdx.x & 63;
-    const unsigned long long window = static_cast<unsigned long long>(blockIdx.x) * (kChunkSortThreads / 64) + (threadIdx.x >> 6);
-    const unsigned long long chunkBase = window * kChunk;
-    if (chunkBase >= a.totalWork)
-    {
-        return;
-    }
-    const uint32_t count = static_cast<uint32_t>(a.totalWork - chunkBase < kChunk ? a.totalWork - chunkBase : kChunk);
-    unsigned char* area = rtSortArea + static_cast<size_t>(threadIdx.x >> 6) * kSortBytesPerWave;
-    unsigned short* sorted = reinterpret_cast<unsigned short*>(area);
-    unsigned short* keys = sorted + kChunk;
-    uint32_t* cells = reinterpret_cast<uint32_t*>(keys + kChunk);
+    const unsigned long long id = static_cast<unsigned long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (id >= a.totalWork) return;
     Rng rng;
     rng.tape = nullptr;
     rng.next = 0;
     rng.seed = a.scene.seed;
-    for (int c = lane; c < kSortCells; c += 64)
-    {
-        cells[c] = 0;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    for (uint32_t j = lane; j < count; j += 64)
-    {
-        double u0, u1;
-        emissionDraws(a, photonAt(a, chunkBase + j), rng, &u0, &u1);
-        const uint32_t key = windowKey(u0, u1, a.emissionOrder != nullptr);
-        keys[j] = static_cast<unsigned short>(key);
-        atomicAdd(&cells[key], 1u);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    // exclusive prefix sum of the cell counts: consecutive cells per lane, then across lanes
-    constexpr int kPerLane = kSortCells / 64;
-    uint32_t sum = 0;
-#pragma unroll 4
-    for (int k = 0; k < kPerLane; ++k)
-    {
-        sum += cells[lane * kPerLane + k];
-    }
-    uint32_t scan = sum;
-#pragma unroll
-    for (int offset = 1; offset < 64; offset <<= 1)
-    {
-        const uint32_t other = __shfl_up(scan, offset, 64);
-        if (lane >= offset) scan += other;
-    }
-    uint32_t running = scan - sum;
-#pragma unroll 4
-    for (int k = 0; k < kPerLane; ++k)
-    {
-        const uint32_t c = cells[lane * kPerLane + k];
-        cells[lane * kPerLane + k] = running;
-        running += c;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    for (uint32_t j = lane; j < count; j += 64)
-    {
-        const uint32_t at = atomicAdd(&cells[keys[j]], 1u);
-        sorted[at] = static_cast<unsigned short>(j);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    for (uint32_t j = lane; j < count; j += 64)
-    {
-        ordered[chunkBase + j] = static_cast<uint32_t>(photonAt(a, chunkBase + sorted[j]));
-    }
+    double u0, u1;
+    emissionDraws(a, id, rng, &u0, &u1);
+    const uint32_t axis = 1u << kGlobalAxisBits;
+    const uint32_t cx = static_cast<uint32_t>(u0 * axis) & (axis - 1);
+    const uint32_t cy = static_cast<uint32_t>(u1 * axis) & (axis - 1);
+    int lightId;
+    unsigned long long photonIndex;
+    splitPhotonId(a, id, &lightId, &photonIndex);
+    keys[id] = (static_cast<uint32_t>(lightId & 0xFF) << (2 * kGlobalAxisBits)) | spreadBits12(cx) | (spreadBits12(cy) << 1);
+    ids[id] = static_cast<uint32_t>(id);
 }
 
 // Sink selects the deposit path and Record the per-photon path dump at compile time, so
@@ -1265,99 +1191,6 @@ __global__ __launch_bounds__(256) void gatherKernel(const GatherArgs a)
     }
 }
 
-// ---------------------------------------------------------------- tile-wise emission-order sort
-// Before a large pass the photon ids are bucketed by emission cell, tile by tile: one block
-// takes 2^kTileBits consecutive ids, counts them per cell of a 128 x 128 Morton grid over the
-// two draws that steer the direction (histogram in LDS), scans the counts and scatters the ids
-// into the tile's own stretch of `order`.  A wave of the trace kernel then claims consecutive
-// positions of `order`, i.e. ids of a few neighbouring cells, and its own sort (sortChunk)
-// orders them within those cells.  No global atomics, and every write lands inside the tile's
-// 1 MB stretch.  Purely a schedule: paths depend on ids only.
-constexpr int kTileThreads = 1024;
-constexpr int kTileCells = 1 << (2 * kTileAxisBits);
-
-RT_DEV uint32_t spreadBits8(uint32_t v)
-{
-    v = (v | (v << 4)) & 0x0F0Fu;
-    v = (v | (v << 2)) & 0x3333u;
-    v = (v | (v << 1)) & 0x5555u;
-    return v;
-}
-
-RT_DEV uint32_t emissionCell(const TraceArgs& a, unsigned long long id, Rng& rng)
-{
-    double u0, u1;
-    emissionDraws(a, id, rng, &u0, &u1);
-    const uint32_t axis = 1u << kTileAxisBits;
-    const uint32_t cx = static_cast<uint32_t>(u0 * axis) & (axis - 1);
-    const uint32_t cy = static_cast<uint32_t>(u1 * axis) & (axis - 1);
-    return spreadBits8(cx) | (spreadBits8(cy) << 1);
-}
-
-__global__ __launch_bounds__(kTileThreads) void emissionTileKernel(const TraceArgs a, uint32_t* order)
-{
-    __shared__ uint32_t cells[kTileCells];
-    __shared__ uint32_t waveTotals[kTileThreads / 64];
-    Rng rng;
-    rng.tape = nullptr;
-    rng.next = 0;
-    rng.seed = a.scene.seed;
-    const unsigned long long tileBase = static_cast<unsigned long long>(blockIdx.x) << kTileBits;
-    const unsigned long long tileEnd =
-        tileBase + (1ull << kTileBits) < a.totalWork ? tileBase + (1ull << kTileBits) : a.totalWork;
-    for (int c = threadIdx.x; c < kTileCells; c += kTileThreads)
-    {
-        cells[c] = 0;
-    }
-    __syncthreads();
-    for (unsigned long long id = tileBase + threadIdx.x; id < tileEnd; id += kTileThreads)
-    {
-        atomicAdd(&cells[emissionCell(a, id, rng)], 1u);
-    }
-    __syncthreads();
-    // exclusive scan of the counts: consecutive cells per thread, then across the block
-    constexpr int kPerThread = kTileCells / kTileThreads;
-    uint32_t sum = 0;
-#pragma unroll
-    for (int k = 0; k < kPerThread; ++k)
-    {
-        sum += cells[threadIdx.x * kPerThread + k];
-    }
-    uint32_t scan = sum;
-#pragma unroll
-    for (int offset = 1; offset < 64; offset <<= 1)
-    {
-        const uint32_t other = __shfl_up(scan, offset, 64);
-        if (static_cast<int>(threadIdx.x & 63) >= offset) scan += other;
-    }
-    if ((threadIdx.x & 63) == 63)
-    {
-        waveTotals[threadIdx.x >> 6] = scan;
-    }
-    __syncthreads();
-    uint32_t before = 0;
-    for (int w = 0; w < static_cast<int>(threadIdx.x >> 6); ++w)
-    {
-        before += waveTotals[w];
-    }
-    uint32_t running = before + scan - sum;
-#pragma unroll
-    for (int k = 0; k < kPerThread; ++k)
-    {
-        const uint32_t c = cells[threadIdx.x * kPerThread + k];
-        cells[threadIdx.x * kPerThread + k] = running;
-        running += c;
-    }
-    __syncthreads();
-    // the cells are recomputed rather than kept: keeping them (and handing the window sort its
-    // keys) was measured slower — the scattered 2- and 4-byte writes cost more than the draws
-    for (unsigned long long id = tileBase + threadIdx.x; id < tileEnd; id += kTileThreads)
-    {
-        const uint32_t at = atomicAdd(&cells[emissionCell(a, id, rng)], 1u);
-        order[tileBase + at] = static_cast<uint32_t>(id);
-    }
-}
-
 // ---------------------------------------------------------------- probe grid build
 // ProbeIndex's constructor (reference src/ProbeIndex.cpp:5-25) hashes every probe into an
 // unordered_map of cells.  Here the probes are keyed by packed cell, sorted, and the runs of
@@ -1531,12 +1364,6 @@ void printDiagnostics()
 }
 #endif
 
-void launchEmissionTiles(const TraceArgs& args, uint32_t* order, hipStream_t stream)
-{
-    const unsigned long long tiles = (args.totalWork + (1ull << kTileBits) - 1) >> kTileBits;
-    hipLaunchKernelGGL(emissionTileKernel, dim3(static_cast<unsigned>(tiles)), dim3(kTileThreads), 0, stream, args, order);
-}
-
 namespace
 {
 
@@ -1572,12 +1399,21 @@ size_t traceLdsBytes(const SceneView& scene)
 
 }  // namespace
 
-void launchChunkSort(const TraceArgs& args, uint32_t* ordered, hipStream_t stream)
+void launchEmissionKeys(const TraceArgs& args, uint32_t* keys, uint32_t* ids, hipStream_t stream)
 {
-    const unsigned long long windows = (args.totalWork + kChunk - 1) / kChunk;
-    const unsigned long long perBlock = kChunkSortThreads / 64;
-    hipLaunchKernelGGL(chunkSortKernel, dim3(static_cast<unsigned>((windows + perBlock - 1) / perBlock)),
-                       dim3(kChunkSortThreads), perBlock * kSortBytesPerWave, stream, args, ordered);
+    hipLaunchKernelGGL(emissionKeysKernel, dim3(gridFor(static_cast<int64_t>(args.totalWork))), dim3(256), 0, stream, args, keys,
+                       ids);
+}
+
+size_t sortEmissionPairs(void* scratch, size_t scratchBytes, const uint32_t* keysIn, uint32_t* keysOut, const uint32_t* idsIn,
+                         uint32_t* idsOut, uint64_t n, int lightCount, hipStream_t stream)
+{
+    size_t bytes = scratchBytes;
+    int lightBits = 0;
+    while ((1 << lightBits) < lightCount && lightBits < 8) ++lightBits;
+    (void)hipcub::DeviceRadixSort::SortPairs(scratch, bytes, keysIn, keysOut, idsIn, idsOut, static_cast<int>(n), 0,
+                                             2 * kGlobalAxisBits + lightBits, stream);
+    return bytes;
 }
 
 void launchTrace(const TraceArgs& args, int blocks, int threads, hipStream_t stream)
