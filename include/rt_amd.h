@@ -143,8 +143,8 @@ int32_t rt_trace(rt_tracer* tracer, const rt_trace_params* params);
 int32_t rt_synchronize(rt_tracer* tracer);
 
 /* Device time of the last rt_trace, from HIP events recorded on the tracer's stream around
- * its two stages: the emission-order sort of the photon ids (0 when the pass was too small
- * to be sorted) and the trace kernel.  The reference reports one wall time for the whole pass
+ * its two stages: the emission-order sort of the photon ids (keys + radix sort; 0 when the
+ * pass has 2^31 ids or more and is traced unsorted) and the trace kernel.  The reference reports one wall time for the whole pass
  * (RenderResult::photonPassSeconds, include/Renderer.h:51-103); the split is what a
  * per-kernel roofline needs.  Waits for the pass to finish. */
 int32_t rt_read_timings(rt_tracer* tracer, float* sort_ms, float* trace_ms);

@@ -222,7 +222,8 @@ def test_probe_sink_store_equals_oracle(rt, scene_opener, name):
 
 @pytest.mark.parametrize("name,photons", [("bombardment", 1_300_000), ("mixed", 250_000)])
 def test_sorted_pass_equals_oracle(rt, scene_opener, name, photons):
-    """Passes of 2^20 photons and more are traced in emission order (tile sort + chunk sort).
+    """Passes are traced in emission order (radix sort of the ids by emission cell, the light above
+    it: the multi-light case interleaves lights in id order but not in the sorted order).
     The schedule must not change any result: same counters, same store multiset, same paths
     for the recorded photons (record slots follow photon ids, not the schedule)."""
     entry = dict(SCENES[name], photons_per_light=photons)
