@@ -121,6 +121,11 @@ double radians(double degrees) { return M_PI * (degrees / 180.0); }  // referenc
 
 }  // namespace
 
+// bounce-level photon queues (see rt_trace)
+constexpr int kQueueLevels = 12;
+constexpr uint64_t kQueueCapacity = 48ull << 20;  // photons parked per level at most (4.5 GB per queue)
+constexpr uint64_t kQueueMinimumWork = 4ull << 20;  // smaller passes are traced in one launch
+
 struct rt_tracer
 {
     int device = 0;
@@ -167,6 +172,9 @@ struct rt_tracer
     DeviceArray<rtd::DeviceCounters> counters;
     // emission-order list of a pass's photon ids
     DeviceArray<uint32_t> sortIds, sortOrder, sortKeysIn, sortKeysOut;
+    DeviceArray<rtd::PhotonState> photonQueue[2];
+
+    DeviceArray<unsigned long long> queueCounts;
     DeviceArray<unsigned char> sortScratch;
     // events around the stages of the last rt_trace: before the sort, after it, after the trace kernel
     hipEvent_t stageEvents[3] = {nullptr, nullptr, nullptr};
@@ -1436,17 +1444,83 @@ int32_t rt_trace(rt_tracer* tracer, const rt_trace_params* params)
         check(hipEventRecord(tracer->stageEvents[1], tracer->stream), "hipEventRecord");
         // the persistent grid fills the chip with the variant this pass runs
         const int residentBlocks = tracer->computeUnits * rtd::traceBlocksPerCu(args);
-        // every resident wave should see several chunks: small passes use small chunks
+        // Bounce by bounce (large passes): the first launch emits the photons and parks those that
+        // go on; each further launch takes the parked photons of the one before.  Photons of
+        // different depth then never share a wave, so the first bounce keeps its emission-order
+        // coherence (sorting the parked photons by origin cell and direction octant was tried as
+        // well: it cost what it gained).  Photons beyond the queues' capacity, or deeper than
+        // kQueueLevels, are followed to their end in their lanes as in a single launch — which is
+        // also what small passes do, where the extra launches cost more than they save.  The count
+        // of parked photons is read back between launches: such a pass is synchronous up to its
+        // last launch.
+        // (RT_AMD_QUEUE_MIN and RT_AMD_QUEUE_CAPACITY override the two limits: tests use them to
+        // take small passes through the queues and through their overflow)
+        uint64_t minimumWork = kQueueMinimumWork, capacityLimit = kQueueCapacity;
+        if (const char* v = std::getenv("RT_AMD_QUEUE_MIN")) minimumWork = std::strtoull(v, nullptr, 10);
+        if (const char* v = std::getenv("RT_AMD_QUEUE_CAPACITY")) capacityLimit = std::max<uint64_t>(1, std::strtoull(v, nullptr, 10));
+        const bool bounceLevels = args.totalWork >= minimumWork;
+        const int levels = bounceLevels ? std::min(kQueueLevels, std::max(0, tracer->settings.bounce_threshold)) : 0;
+        const uint64_t capacity = levels > 0 ? std::min<uint64_t>(args.totalWork, capacityLimit) : 0;
+        if (capacity > 0 && tracer->photonQueue[0].count < capacity)
         {
-            const uint64_t waves = static_cast<uint64_t>(residentBlocks) * 4;
-            uint64_t chunk = args.totalWork / (waves * 4);
-            chunk = std::min<uint64_t>(4096, std::max<uint64_t>(64, chunk)) & ~63ull;
-            args.chunk = static_cast<uint32_t>(chunk);
+            tracer->photonQueue[0].allocate(capacity);
+            tracer->photonQueue[1].allocate(capacity);
         }
-        const uint64_t wavesNeeded = (args.totalWork + 63) / 64;
-        const int blocks = static_cast<int>(std::min<uint64_t>(static_cast<uint64_t>(residentBlocks), (wavesNeeded + 3) / 4));
-        rtd::launchTrace(args, std::max(1, blocks), 256, tracer->stream);
-        check(hipGetLastError(), "trace launch");
+        if (levels > 0 && tracer->queueCounts.count == 0)
+        {
+            tracer->queueCounts.allocate(static_cast<size_t>(2 * (kQueueLevels + 1)));
+        }
+        if (levels > 0)
+        {
+            tracer->queueCounts.zero(tracer->stream);
+        }
+        uint64_t parked = 0;  // photons in the queue the next launch reads
+        for (int level = 0; level <= levels; ++level)
+        {
+            rtd::TraceArgs launch = args;
+            // per level: [2 * level] = slots claimed in the queue this level fills, [2 * level + 1] = its work counter
+            unsigned long long* counts = tracer->queueCounts.ptr;
+            uint64_t work = args.totalWork;
+            if (level > 0)
+            {
+                launch.queueIn = tracer->photonQueue[(level - 1) & 1].ptr;
+                launch.queueInCount = parked;
+                launch.workCounter = counts + 2 * level + 1;
+                launch.emissionOrder = nullptr;
+                work = parked;
+            }
+            if (level < levels)
+            {
+                launch.queueOut = tracer->photonQueue[level & 1].ptr;
+                launch.queueOutCount = counts + 2 * level;
+                launch.queueOutCapacity = capacity;
+            }
+            // every resident wave should see several runs: small launches use short runs
+            {
+                const uint64_t waves = static_cast<uint64_t>(residentBlocks) * 4;
+                uint64_t chunk = work / (waves * 4);
+                // parked photons are in no particular order: short runs, for balance
+                chunk = std::min<uint64_t>(level > 0 ? 256 : 4096, std::max<uint64_t>(64, chunk)) & ~63ull;
+                launch.chunk = static_cast<uint32_t>(chunk);
+            }
+            const uint64_t wavesNeeded = (work + 63) / 64;
+            const int blocks = static_cast<int>(std::min<uint64_t>(static_cast<uint64_t>(residentBlocks), (wavesNeeded + 3) / 4));
+            rtd::launchTrace(launch, std::max(1, blocks), 256, tracer->stream);
+            check(hipGetLastError(), "trace launch");
+            if (level == levels)
+            {
+                break;
+            }
+            unsigned long long claimed = 0;
+            check(hipMemcpyAsync(&claimed, counts + 2 * level, sizeof(claimed), hipMemcpyDeviceToHost, tracer->stream),
+                  "hipMemcpyAsync queue count");
+            check(hipStreamSynchronize(tracer->stream), "hipStreamSynchronize");
+            parked = std::min<uint64_t>(claimed, capacity);
+            if (parked == 0)
+            {
+                break;
+            }
+        }
         check(hipEventRecord(tracer->stageEvents[2], tracer->stream), "hipEventRecord");
         tracer->timed = true;
     });

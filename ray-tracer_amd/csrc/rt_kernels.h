@@ -88,6 +88,18 @@ struct RecordView
     float* power;         // [M][B][3]
 };
 
+// A photon between two bounces, parked in a queue so that the next bounce of all photons of a
+// pass runs as a launch of its own (photons of different depth do not share waves).
+struct alignas(16) PhotonState
+{
+    double origin[3], direction[3];
+    float color[3], time;
+    unsigned long long photonIndex;
+    long long recordSlot;
+    int32_t lightId, bounces, casts, valid;
+};
+static_assert(sizeof(PhotonState) == 96, "PhotonState layout");
+
 struct TraceArgs
 {
     SceneView scene;
@@ -104,12 +116,19 @@ struct TraceArgs
     uint64_t totalWork;    // lights * photonCount
     double minSplatRadius;
     int32_t sinkMode;
+    // bounce-level queues (all null: photons are emitted from ids and followed to their end)
+    const PhotonState* queueIn;               // work of this launch: parked photons instead of ids
+    uint64_t queueInCount;                    // how many
+    PhotonState* queueOut;                    // photons that go on after this launch's bounce are parked here
+    unsigned long long* queueOutCount;        // slots claimed (may exceed queueOutCapacity)
+    uint64_t queueOutCapacity;                // beyond it a photon is followed on in its lane
 };
 
 void launchTrace(const TraceArgs& args, int blocks, int threads, hipStream_t stream);
 // Whole-pass emission order: keys and ids of every photon of the pass, then a radix sort of the pairs
 // (returns the scratch bytes needed when scratch is null).
 void launchEmissionKeys(const TraceArgs& args, uint32_t* keys, uint32_t* ids, hipStream_t stream);
+
 size_t sortEmissionPairs(void* scratch, size_t scratchBytes, const uint32_t* keysIn, uint32_t* keysOut, const uint32_t* idsIn,
                          uint32_t* idsOut, uint64_t n, int lightCount, hipStream_t stream);
 void launchCastRays(const SceneView& scene, int64_t n, const double* rays, double selfHit, double* outF64,

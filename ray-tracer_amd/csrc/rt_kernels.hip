@@ -471,7 +471,14 @@ __global__ __launch_bounds__(kTraceThreads) void traceKernel(const TraceArgs a)
     RT_DIAG_WAVE_BEGIN;
     RT_DIAG_TIC(kernelStart);
 
-    // this wave's run of positions in the pass's emission-ordered id list
+    // work of this launch: the pass's emission-ordered id list, or the photons parked by the
+    // launch of the previous bounce
+    unsigned long long totalWork = a.totalWork;
+    if (a.queueIn)
+    {
+        totalWork = a.queueInCount;
+    }
+    // this wave's run of positions in that list
     unsigned long long chunkBase = 0;     // wave-uniform
     uint32_t chunkNext = 0, chunkCount = 0;
     bool exhausted = false;               // the global id range is used up (wave-uniform)
@@ -516,8 +523,8 @@ __global__ __launch_bounds__(kTraceThreads) void traceKernel(const TraceArgs a)
                 }
                 chunkBase = __shfl(fresh, 0, 64);
                 chunkNext = 0;
-                chunkCount = chunkBase < a.totalWork
-                                 ? static_cast<uint32_t>(a.totalWork - chunkBase < a.chunk ? a.totalWork - chunkBase : a.chunk)
+                chunkCount = chunkBase < totalWork
+                                 ? static_cast<uint32_t>(totalWork - chunkBase < a.chunk ? totalWork - chunkBase : a.chunk)
                                  : 0u;
                 exhausted = chunkCount == 0;
             }
@@ -525,13 +532,29 @@ __global__ __launch_bounds__(kTraceThreads) void traceKernel(const TraceArgs a)
             const uint32_t avail = chunkCount - chunkNext;
             const uint32_t n = static_cast<uint32_t>(__builtin_popcountll(needMask));
             const bool served = need && rank < avail;
-            const unsigned long long id = served ? photonAt(a, chunkBase + chunkNext + rank) : a.totalWork;
+            const unsigned long long position = chunkBase + chunkNext + rank;
+            const unsigned long long id = (served && !a.queueIn) ? photonAt(a, position) : 0ull;
             chunkNext += n < avail ? n : avail;
             if (need && !served && exhausted)
             {
                 finished = true;
             }
-            if (served)
+            if (served && a.queueIn)
+            {
+                const PhotonState& parked = a.queueIn[position];
+                ray.o = mk(parked.origin[0], parked.origin[1], parked.origin[2]);
+                ray.d = mk(parked.direction[0], parked.direction[1], parked.direction[2]);
+                color = Color{parked.color[0], parked.color[1], parked.color[2]};
+                time = parked.time;
+                photonIndex = parked.photonIndex;
+                recordSlot = parked.recordSlot;
+                lightId = parked.lightId;
+                bounces = parked.bounces;
+                casts = parked.casts;
+                valid = parked.valid;
+                alive = true;
+            }
+            else if (served)
             {
                 {
                     splitPhotonId(a, id, &lightId, &photonIndex);
@@ -580,6 +603,7 @@ __global__ __launch_bounds__(kTraceThreads) void traceKernel(const TraceArgs a)
         }
 
         // ---- one bounce (Worker::processPhotons loop body, src/Worker.cpp:530-673) ----
+        bool goesOn = false;  // the photon left this bounce with a new ray
         if (alive)
         {
             RT_DIAG_TRIP(8);
@@ -678,6 +702,7 @@ __global__ __launch_bounds__(kTraceThreads) void traceKernel(const TraceArgs a)
                         ray.d = smp.direction;
                         color = color * smp.weight;
                     }
+                    goesOn = true;
                 }
                 RT_DIAG_TOC(scatterStart, 6);
             }
@@ -697,6 +722,37 @@ __global__ __launch_bounds__(kTraceThreads) void traceKernel(const TraceArgs a)
                 lc.casts += static_cast<unsigned long long>(casts);
                 lc.bounces += static_cast<unsigned long long>(valid);
                 alive = false;
+            }
+        }
+        // ---- park the photons that go on: their next bounce belongs to the next launch ----
+        if (a.queueOut)
+        {
+            const unsigned long long parkMask = __ballot(goesOn);
+            if (parkMask != 0)
+            {
+                const int leader = __builtin_ctzll(parkMask);
+                unsigned long long base = 0;
+                if (lane == leader)
+                {
+                    base = atomicAdd(a.queueOutCount, static_cast<unsigned long long>(__builtin_popcountll(parkMask)));
+                }
+                base = __shfl(base, leader, 64);
+                const unsigned long long slot = base + lanesBelow(parkMask);
+                if (goesOn && slot < a.queueOutCapacity)  // a full queue: the photon stays in its lane
+                {
+                    PhotonState& parked = a.queueOut[slot];
+                    parked.origin[0] = ray.o.x; parked.origin[1] = ray.o.y; parked.origin[2] = ray.o.z;
+                    parked.direction[0] = ray.d.x; parked.direction[1] = ray.d.y; parked.direction[2] = ray.d.z;
+                    parked.color[0] = color.r; parked.color[1] = color.g; parked.color[2] = color.b;
+                    parked.time = time;
+                    parked.photonIndex = photonIndex;
+                    parked.recordSlot = recordSlot;
+                    parked.lightId = lightId;
+                    parked.bounces = bounces;
+                    parked.casts = casts;
+                    parked.valid = valid;
+                    alive = false;
+                }
             }
         }
     }

@@ -163,7 +163,7 @@ def test_photon_paths_bit_exact_vs_oracle(rt, scene_opener, name):
     assert np.allclose(counters["deposited_power"], ref["deposited_power"], rtol=1e-9)
 
 
-@pytest.mark.parametrize("name,photons", [("bombardment", 4_000_000), ("knot", 2_000_000), ("cbgmd", 1_500_000)])
+@pytest.mark.parametrize("name,photons", [("bombardment", 4_000_000), ("knot", 5_000_000), ("cbgmd", 1_500_000)])
 def test_counters_equal_oracle_at_scale(rt, scene_opener, name, photons):
     """The device walks its own trees (surface-area splits, padded single-precision boxes, several
     triangles per leaf) and must still report the hits of the reference's exhaustive walk of its
@@ -182,6 +182,38 @@ def test_counters_equal_oracle_at_scale(rt, scene_opener, name, photons):
     assert_bits_equal(got["bounce_f64"], ref["bounce_f64"], "hits")
     assert np.array_equal(got["bounce_i32"], ref["bounce_i32"]), "ids"
     assert np.allclose(c["deposited_power"], ref["deposited_power"], rtol=1e-9)
+
+
+@pytest.mark.parametrize("capacity", [1 << 30, 700])
+@pytest.mark.parametrize("name", ["cbgmd", "knot", "mixed", "animated", "furnace"])
+def test_bounce_level_queues_change_nothing(rt, scene_opener, name, capacity, monkeypatch):
+    """Large passes park the photons that go on after a bounce and trace the next bounce in a
+    launch of its own; a full queue leaves a photon in its lane.  Forced onto small passes here
+    (queue minimum 1), with room for everything and with room for 700 photons per level: paths,
+    counters and the store must equal the oracle's as in a single launch."""
+    monkeypatch.setenv("RT_AMD_QUEUE_MIN", "1")
+    monkeypatch.setenv("RT_AMD_QUEUE_CAPACITY", str(capacity))
+    entry = SCENES[name]
+    scene, tracer, orc = _open(rt, scene_opener, entry)
+    total = entry["photons_per_light"] * scene.desc.light_count
+    pre = orc.trace(rng_mode=O.RNG_COUNTER, math_mode=O.MATH_PORTABLE, threads=8, record_photons=600)
+    probes = pre["bounce_f64"][:, 0, :3][pre["casts_valid"][:, 1] > 0][::3]
+    keep = 12.0
+    ref = orc.trace(rng_mode=O.RNG_COUNTER, math_mode=O.MATH_PORTABLE, threads=8, sink_mode=O.SINK_PROBE, probes=probes,
+                    probe_cell_size=keep, keep_radius=keep, store_capacity=1 << 18, record_photons=total)
+    tracer.set_probes(probes, keep, keep, 1 << 18)
+    tracer.reset()
+    tracer.trace(sink_mode=1, record_photons=total)
+    got = tracer.records()
+    c = tracer.counters()
+    assert ref["bounces"] > ref["photons"], "the scene must have photons that go on"
+    for k in ("photons", "casts", "bounces", "deposits", "kept", "culled", "store_size"):
+        assert c[k] == ref[k], k
+    assert np.array_equal(got["casts_valid"], ref["casts_valid"]), "casts / bounce counts"
+    assert_bits_equal(got["bounce_f64"], ref["bounce_f64"], "hits")
+    assert np.array_equal(got["bounce_i32"], ref["bounce_i32"]), "ids"
+    assert_bits_equal(got["bounce_power"], ref["bounce_power"], "power")
+    assert_bits_equal(_sorted_records(tracer.store()), _sorted_records(ref["store"]), "store records")
 
 
 def _sorted_records(store):
