@@ -137,8 +137,12 @@ int32_t rt_reset(rt_tracer* tracer);
 
 /* The photon pass: emit and trace the photon range of every light (reference
  * Worker::exec / processLights / processPhotons, src/Worker.cpp:116-174,429-680).
- * Asynchronous on the handle's stream; accumulates into sinks and counters until
- * rt_reset. */
+ * Runs on the handle's stream and accumulates into sinks and counters until rt_reset.
+ * The photon ids of the pass are first put in emission order (a schedule only: a photon's
+ * path depends on its id, not on when it is traced).  A pass of 4 Mi photons or more is
+ * traced one bounce level per launch and the host waits between launches for the count of
+ * photons that go on, so rt_trace returns when the last launch has been queued; a smaller
+ * pass is one launch and rt_trace returns at once.  rt_synchronize waits for either. */
 int32_t rt_trace(rt_tracer* tracer, const rt_trace_params* params);
 int32_t rt_synchronize(rt_tracer* tracer);
 
