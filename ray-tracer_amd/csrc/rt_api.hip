@@ -280,14 +280,16 @@ void buildScene(rt_tracer* t, const rt_scene* scene)
         const double* pos = scene->tri_pos + 9 * mesh.first_triangle;
         const double* nrm = scene->tri_nrm + 9 * mesh.first_triangle;
         // the reference's tree gives every triangle its visiting rank and node box; the tree the
-        // device walks is built over the same triangles.  Padding: far above the rounding of a slab
-        // test on coordinates of this size, far below anything that would cost traversal steps.
+        // device walks is built over the same triangles.  Its boxes are tested in single precision
+        // against ray origins anywhere in the scene: padding of a few millionths of the scene's
+        // scale is an order of magnitude above what that loses (6e-8 of the origin's size in the
+        // origin, 2e-7 of a plane's distance in the products), and costs no traversal steps.
         double extent = 0.0;
         for (int64_t i = 0; i < 9 * mesh.triangle_count; ++i)
         {
             extent = std::max(extent, std::fabs(pos[i]));
         }
-        const double pad = 1e-7 * extent + 1e-10 * sceneScale;
+        const double pad = 4e-6 * sceneScale;
         const rtbvh::FlatMesh flat =
             rtbvh::buildSurfaceArea(pos, mesh.triangle_count, rtbvh::build(pos, mesh.triangle_count), pad, leafSize);
         const rtbvh::WideMesh wide = rtbvh::widen(flat);

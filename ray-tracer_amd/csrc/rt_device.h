@@ -589,24 +589,52 @@ RT_DEV TraversalStack laneStack()
     return TraversalStack{rtTraversalStack + threadIdx.x, static_cast<int32_t>(blockDim.x)};
 }
 
-// Slab test of one child box of a node (six floats, widened exactly): the same interval
-// arithmetic as slabTest; the plane the ray meets first is picked by the direction's sign.
-RT_DEV bool slabTestChild(const Ray& ray, const RayPrep& p, const float* box, double* entry)
+// Slab test of one child box of a node, in single precision with packed operations.  The
+// boxes are grown (on the host) by far more than single precision loses on coordinates of the
+// scene's size, so that every parameter interval computed here CONTAINS the true one: a box
+// the ray meets is never reported as missed, and the entry parameter is never over-estimated.
+// Which hit is reported does not depend on these boxes (see castMesh).
+typedef float Float2 __attribute__((ext_vector_type(2)));
+
+struct RayPrepSingle
 {
-    double tmin = 0.0;
-    double tmax = kMaxDouble;
+    // origin and reciprocal direction paired the way a box's six planes lie in memory:
+    // (lo x, lo y) (lo z, hi x) (hi y, hi z)
+    Float2 oA, oB, oC, dA, dB, dC;
+};
+
+RT_DEV RayPrepSingle prepareRaySingle(const Ray& ray, const RayPrep& p)
+{
+    float o[3], d[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i)
     {
-        const double origin = axisOf(ray.o, i);
-        const bool reversed = p.nearIdx[i] != i;
-        const float nearPlane = reversed ? box[3 + i] : box[i];
-        const float farPlane = reversed ? box[i] : box[3 + i];
-        const double tnear = (static_cast<double>(nearPlane) - origin) * p.ood[i];
-        const double tfar = (static_cast<double>(farPlane) - origin) * p.ood[i];
-        tmin = __builtin_fmax(tmin, tnear);
-        tmax = __builtin_fmin(tmax, tfar);
+        o[i] = static_cast<float>(axisOf(ray.o, i));
+        // an axis the ray runs parallel to: a huge finite reciprocal keeps 0 * reciprocal at 0, so
+        // an origin between (or on) the planes gives (-huge, +huge) and one outside an empty interval
+        const float r = static_cast<float>(p.ood[i]);
+        d[i] = __builtin_fminf(__builtin_fmaxf(r, -1e30f), 1e30f);
     }
+    RayPrepSingle q;
+    q.oA = Float2{o[0], o[1]};
+    q.oB = Float2{o[2], o[0]};
+    q.oC = Float2{o[1], o[2]};
+    q.dA = Float2{d[0], d[1]};
+    q.dB = Float2{d[2], d[0]};
+    q.dC = Float2{d[1], d[2]};
+    return q;
+}
+
+RT_DEV bool slabTestChild(const RayPrepSingle& q, const float* box, float* entry)
+{
+    const Float2 tA = (Float2{box[0], box[1]} - q.oA) * q.dA;  // lo x, lo y
+    const Float2 tB = (Float2{box[2], box[3]} - q.oB) * q.dB;  // lo z, hi x
+    const Float2 tC = (Float2{box[4], box[5]} - q.oC) * q.dC;  // hi y, hi z
+    const float nearX = __builtin_fminf(tA.x, tB.y), farX = __builtin_fmaxf(tA.x, tB.y);
+    const float nearY = __builtin_fminf(tA.y, tC.x), farY = __builtin_fmaxf(tA.y, tC.x);
+    const float nearZ = __builtin_fminf(tB.x, tC.y), farZ = __builtin_fmaxf(tB.x, tC.y);
+    const float tmin = __builtin_fmaxf(0.0f, __builtin_fmaxf(nearX, __builtin_fmaxf(nearY, nearZ)));
+    const float tmax = __builtin_fminf(farX, __builtin_fminf(farY, farZ));
     *entry = tmin;
     return !(tmin > tmax);
 }
@@ -646,6 +674,9 @@ RT_DEV bool castMesh(const SceneView& s, int32_t nodeBase, int32_t nodeCount, in
     double best = kMaxDouble;
     int32_t bestSlot = 0x7fffffff, bestRank = 0x7fffffff;
     double cutoff = bound * (1.0 + 1e-9) + slack;  // kMaxDouble -> +inf: nothing is pruned
+    // the same bound as a ray parameter in single precision, rounded up (never prunes too much)
+    float cutoffT = __double2float_ru(cutoff / dlen);
+    const RayPrepSingle single = prepareRaySingle(ray, prep);
 
     constexpr int32_t kDone = kNoChild;    // nothing left to visit
     constexpr int32_t kPop = kNoChild + 1;  // take the next entry of the stack
@@ -689,16 +720,16 @@ RT_DEV bool castMesh(const SceneView& s, int32_t nodeBase, int32_t nodeCount, in
                     left = links.x;
                     right = links.y;
                 }
-                double el, er;
-                bool okl = slabTestChild(ray, prep, leftBox, &el);
-                bool okr = slabTestChild(ray, prep, rightBox, &er);
-                okl = okl && left != kNoChild && !(el * dlen > cutoff);
-                okr = okr && right != kNoChild && !(er * dlen > cutoff);
+                float el, er;
+                bool okl = slabTestChild(single, leftBox, &el);
+                bool okr = slabTestChild(single, rightBox, &er);
+                okl = okl && left != kNoChild && !(el > cutoffT);
+                okr = okr && right != kNoChild && !(er > cutoffT);
                 if (okl && okr)
                 {
                     const bool leftNear = el <= er;
                     const int32_t farChild = leftNear ? right : left;
-                    const float farEntry = __double2float_rd(leftNear ? er : el);
+                    const float farEntry = leftNear ? er : el;
                     stack.base[sp * stack.stride] =
                         (static_cast<unsigned long long>(static_cast<uint32_t>(farChild)) << 32) | __float_as_uint(farEntry);
                     sp += 1;
@@ -716,8 +747,7 @@ RT_DEV bool castMesh(const SceneView& s, int32_t nodeBase, int32_t nodeCount, in
                 {
                     sp -= 1;
                     const unsigned long long e = stack.base[sp * stack.stride];
-                    const double entry = static_cast<double>(__uint_as_float(static_cast<uint32_t>(e)));
-                    if (!(entry * dlen > cutoff))
+                    if (!(__uint_as_float(static_cast<uint32_t>(e)) > cutoffT))
                     {
                         cur = static_cast<int32_t>(e >> 32);
                         break;
@@ -774,6 +804,7 @@ RT_DEV bool castMesh(const SceneView& s, int32_t nodeBase, int32_t nodeCount, in
                     bary[2] = b3[2];
                     *position = pos;
                     cutoff = dmin(best, bound) * (1.0 + 1e-9) + slack;
+                    cutoffT = __double2float_ru(cutoff / dlen);
                 }
             }
         }
