@@ -120,6 +120,15 @@ int32_t rt_set_stream(rt_tracer* tracer, void* hip_stream);
 int32_t rt_set_probes(rt_tracer* tracer, const double* probes, uint64_t n, double cell_size,
                       double keep_radius, uint64_t store_capacity);
 
+/* Sink A set up without leaving the device: the probes are the positions of the probe-pass
+ * records of every camera that takes part in the gather (those without a bounce or light
+ * filter), as Renderer::renderFrame collects them (reference src/Renderer.cpp:297-371), and
+ * the store holds min(max_store_capacity, records_per_probe x probes) records (:382-390; all
+ * of max_store_capacity when there is no probe).  Same result as rt_collect_gather_points for
+ * each camera followed by rt_set_probes, without the round trip of the records through the host. */
+int32_t rt_set_probes_from_cameras(rt_tracer* tracer, double cell_size, double keep_radius, uint64_t records_per_probe,
+                                   uint64_t max_store_capacity, uint64_t* probe_count, uint64_t* store_capacity);
+
 /* Sink B set-up: Worker::setMinSplatRadius / setSplatTargets / the DensityGrid
  * (reference src/Renderer.cpp:196-274,445-457).  density_cell_size <= 0 disables the
  * grid; density_capacity is the number of hash slots reserved for occupied cells. */

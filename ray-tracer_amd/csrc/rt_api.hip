@@ -195,7 +195,9 @@ struct rt_tracer
         DeviceArray<uint32_t> counts;
         DeviceArray<uint64_t> offsets;
         DeviceArray<rtd::GatherPoint> devicePoints;
-        std::vector<rtd::GatherPoint> points;
+        uint64_t total = 0;                     // records on the device
+        std::vector<rtd::GatherPoint> points;   // host copy, made when first asked for
+        bool hostCopied = false;
         uint64_t stats[3] = {0, 0, 0};
     };
     std::vector<std::unique_ptr<GatherCache>> gatherCache;
@@ -727,17 +729,15 @@ rt_tracer::GatherCache& ensureGatherPoints(rt_tracer* tracer, int32_t camera)
         total += hostCounts[i];
     }
     cache.offsets.upload(hostOffsets);
-    cache.points.assign(static_cast<size_t>(total), rtd::GatherPoint{});
+    cache.total = total;
+    cache.points.clear();
+    cache.hostCopied = false;
     cache.devicePoints.allocate(static_cast<size_t>(total));
     if (total > 0)
     {
         rtd::launchGatherWrite(tracer->view, camera, stride, pixels, cache.counts.ptr, cache.offsets.ptr,
                                cache.devicePoints.ptr, tracer->stream);
         check(hipGetLastError(), "gather write launch");
-        check(hipMemcpyAsync(cache.points.data(), cache.devicePoints.ptr, total * sizeof(rtd::GatherPoint),
-                             hipMemcpyDeviceToHost, tracer->stream),
-              "hipMemcpyAsync gather points");
-        check(hipStreamSynchronize(tracer->stream), "hipStreamSynchronize");
     }
     for (int k = 0; k < 3; ++k)
     {
@@ -747,10 +747,29 @@ rt_tracer::GatherCache& ensureGatherPoints(rt_tracer* tracer, int32_t camera)
     return cache;
 }
 
+// The probe pass's records on the host (copied once, when a caller wants to read them).
+const std::vector<rtd::GatherPoint>& hostGatherPoints(rt_tracer* tracer, rt_tracer::GatherCache& cache)
+{
+    if (!cache.hostCopied)
+    {
+        cache.points.assign(static_cast<size_t>(cache.total), rtd::GatherPoint{});
+        if (cache.total > 0)
+        {
+            check(hipMemcpyAsync(cache.points.data(), cache.devicePoints.ptr, cache.total * sizeof(rtd::GatherPoint),
+                                 hipMemcpyDeviceToHost, tracer->stream),
+                  "hipMemcpyAsync gather points");
+            check(hipStreamSynchronize(tracer->stream), "hipStreamSynchronize");
+        }
+        cache.hostCopied = true;
+    }
+    return cache.points;
+}
+
 // Device-side build of the probe grid.  Returns false (nothing changed) when the general host
 // build must be used: a keep radius that spans more than one cell, or cell coordinates beyond
 // the packable +-2^20 range.
-bool buildProbesOnDevice(rt_tracer* tracer, const double* probes, uint64_t n, double invCellSize, double keepRadius)
+bool buildProbesOnDevice(rt_tracer* tracer, const double* probes, bool probesOnDevice, uint64_t n, double invCellSize,
+                         double keepRadius)
 {
     const int64_t reach = static_cast<int64_t>(std::ceil(keepRadius * invCellSize));
     if (n == 0 || reach != 1 || n >= (1ull << 31) / 27)
@@ -771,7 +790,9 @@ bool buildProbesOnDevice(rt_tracer* tracer, const double* probes, uint64_t n, do
     scalars.allocate(2);
     flag.zero(stream);
     scalars.zero(stream);
-    check(hipMemcpyAsync(points.ptr, probes, 3 * n * sizeof(double), hipMemcpyHostToDevice, stream), "hipMemcpyAsync probes");
+    check(hipMemcpyAsync(points.ptr, probes, 3 * n * sizeof(double),
+                         probesOnDevice ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, stream),
+          "hipMemcpyAsync probes");
     rtd::ProbeBuild build{points.ptr, n, invCellSize, keysIn.ptr, orderIn.ptr};
     rtd::launchProbeKeys(build, flag.ptr, stream);
     uint32_t unpackable = 0;
@@ -1151,6 +1172,100 @@ int32_t rt_set_stream(rt_tracer* tracer, void* hip_stream)
     });
 }
 
+namespace
+{
+
+// ProbeIndex's constructor and the BounceStore behind it (reference src/ProbeIndex.cpp:5-25,
+// src/Renderer.cpp:372-392) from `n` positions in host or device memory.
+void setProbes(rt_tracer* tracer, const double* probes, bool probesOnDevice, uint64_t n, double cell_size, double keep_radius,
+               uint64_t store_capacity)
+{
+    // ProbeIndex constructor, reference src/ProbeIndex.cpp:5-16
+    const double cellSize = cell_size > 0.0 ? cell_size : 1.0;
+    const double invCellSize = 1.0 / cellSize;
+    const double keepRadius = keep_radius > 0.0 ? keep_radius : 0.0;
+    tracer->storeCapacity = store_capacity;
+    tracer->storeRecords.allocate(static_cast<size_t>(store_capacity) * 13);
+    // the usual case (one cell of reach, coordinates that pack) is built on the device
+    if (buildProbesOnDevice(tracer, probes, probesOnDevice, n, invCellSize, keepRadius))
+    {
+        tracer->probesSet = true;
+        return;
+    }
+    // the general build works on the host
+    std::vector<double> fetched;
+    if (probesOnDevice && n > 0)
+    {
+        fetched.resize(static_cast<size_t>(3 * n));
+        check(hipMemcpy(fetched.data(), probes, fetched.size() * sizeof(double), hipMemcpyDeviceToHost), "hipMemcpy probes");
+        probes = fetched.data();
+    }
+    std::map<CellKey, std::vector<uint32_t>> cells;
+    for (uint64_t i = 0; i < n; ++i)
+    {
+        const CellKey key{static_cast<int64_t>(std::floor(probes[3 * i] * invCellSize)),
+                          static_cast<int64_t>(std::floor(probes[3 * i + 1] * invCellSize)),
+                          static_cast<int64_t>(std::floor(probes[3 * i + 2] * invCellSize))};
+        cells[key].push_back(static_cast<uint32_t>(i));
+    }
+    uint64_t slots = 16;
+    while (slots < 2 * cells.size() + 1)
+    {
+        slots <<= 1;
+    }
+    std::vector<int64_t> slotKey(3 * slots, 0);
+    std::vector<uint32_t> slotStart(slots, 0), slotCount(slots, 0);
+    std::vector<double> points;
+    points.reserve(3 * n);
+    for (const auto& cell : cells)
+    {
+        uint64_t slot = cellSlot(cell.first, slots - 1);
+        while (slotCount[slot] != 0)
+        {
+            slot = (slot + 1) & (slots - 1);
+        }
+        slotKey[3 * slot + 0] = cell.first.x;
+        slotKey[3 * slot + 1] = cell.first.y;
+        slotKey[3 * slot + 2] = cell.first.z;
+        slotStart[slot] = static_cast<uint32_t>(points.size() / 3);
+        slotCount[slot] = static_cast<uint32_t>(cell.second.size());
+        for (uint32_t index : cell.second)
+        {
+            points.insert(points.end(), probes + 3 * index, probes + 3 * index + 3);
+        }
+    }
+    tracer->slotKey.upload(slotKey);
+    tracer->slotStart.upload(slotStart);
+    tracer->slotCount.upload(slotCount);
+    tracer->probePoints.upload(points);
+    rtd::ProbeView& pv = tracer->probeView;
+    pv.slotKey = tracer->slotKey.ptr;
+    pv.slotStart = tracer->slotStart.ptr;
+    pv.slotCount = tracer->slotCount.ptr;
+    pv.points = tracer->probePoints.ptr;
+    pv.slotMask = slots - 1;
+    pv.probeCount = n;
+    pv.invCellSize = invCellSize;
+    pv.keepRadius = keepRadius;
+    pv.reach = static_cast<int64_t>(std::ceil(keepRadius * invCellSize));
+    require(pv.reach <= 64, "keep radius spans too many probe cells");
+
+    // no neighbourhood filter on this path (the device build above makes it whenever it applies):
+    // the keep test scans the cells within reach
+    pv.nearKey = nullptr;
+    pv.nearBits = nullptr;
+    pv.nearMask = 0;
+    pv.packedCells = nullptr;
+    pv.nearEntries = nullptr;
+    tracer->nearKey.release();
+    tracer->nearBits.release();
+    tracer->packedCells.release();
+    tracer->nearEntries.release();
+    tracer->probesSet = true;
+}
+
+}  // namespace
+
 int32_t rt_set_probes(rt_tracer* tracer, const double* probes, uint64_t n, double cell_size, double keep_radius,
                       uint64_t store_capacity)
 {
@@ -1159,132 +1274,43 @@ int32_t rt_set_probes(rt_tracer* tracer, const double* probes, uint64_t n, doubl
         require(n == 0 || probes != nullptr, "probes is null");
         require(n < (1ull << 32), "too many probes");
         activate(tracer);
-        // ProbeIndex constructor, reference src/ProbeIndex.cpp:5-16
-        const double cellSize = cell_size > 0.0 ? cell_size : 1.0;
-        const double invCellSize = 1.0 / cellSize;
-        const double keepRadius = keep_radius > 0.0 ? keep_radius : 0.0;
-        tracer->storeCapacity = store_capacity;
-        tracer->storeRecords.allocate(static_cast<size_t>(store_capacity) * 13);
-        // the usual case (one cell of reach, coordinates that pack) is built on the device
-        if (buildProbesOnDevice(tracer, probes, n, invCellSize, keepRadius))
-        {
-            tracer->probesSet = true;
-            return;
-        }
-        std::map<CellKey, std::vector<uint32_t>> cells;
-        for (uint64_t i = 0; i < n; ++i)
-        {
-            const CellKey key{static_cast<int64_t>(std::floor(probes[3 * i] * invCellSize)),
-                              static_cast<int64_t>(std::floor(probes[3 * i + 1] * invCellSize)),
-                              static_cast<int64_t>(std::floor(probes[3 * i + 2] * invCellSize))};
-            cells[key].push_back(static_cast<uint32_t>(i));
-        }
-        uint64_t slots = 16;
-        while (slots < 2 * cells.size() + 1)
-        {
-            slots <<= 1;
-        }
-        std::vector<int64_t> slotKey(3 * slots, 0);
-        std::vector<uint32_t> slotStart(slots, 0), slotCount(slots, 0);
-        std::vector<double> points;
-        points.reserve(3 * n);
-        for (const auto& cell : cells)
-        {
-            uint64_t slot = cellSlot(cell.first, slots - 1);
-            while (slotCount[slot] != 0)
-            {
-                slot = (slot + 1) & (slots - 1);
-            }
-            slotKey[3 * slot + 0] = cell.first.x;
-            slotKey[3 * slot + 1] = cell.first.y;
-            slotKey[3 * slot + 2] = cell.first.z;
-            slotStart[slot] = static_cast<uint32_t>(points.size() / 3);
-            slotCount[slot] = static_cast<uint32_t>(cell.second.size());
-            for (uint32_t index : cell.second)
-            {
-                points.insert(points.end(), probes + 3 * index, probes + 3 * index + 3);
-            }
-        }
-        tracer->slotKey.upload(slotKey);
-        tracer->slotStart.upload(slotStart);
-        tracer->slotCount.upload(slotCount);
-        tracer->probePoints.upload(points);
-        rtd::ProbeView& pv = tracer->probeView;
-        pv.slotKey = tracer->slotKey.ptr;
-        pv.slotStart = tracer->slotStart.ptr;
-        pv.slotCount = tracer->slotCount.ptr;
-        pv.points = tracer->probePoints.ptr;
-        pv.slotMask = slots - 1;
-        pv.probeCount = n;
-        pv.invCellSize = invCellSize;
-        pv.keepRadius = keepRadius;
-        pv.reach = static_cast<int64_t>(std::ceil(keepRadius * invCellSize));
-        require(pv.reach <= 64, "keep radius spans too many probe cells");
+        setProbes(tracer, probes, false, n, cell_size, keep_radius, store_capacity);
+    });
+}
 
-        // neighbourhood filter: which cells have an occupied cell among their 27 neighbours
-        pv.nearKey = nullptr;
-        pv.nearBits = nullptr;
-        pv.nearMask = 0;
-        tracer->nearKey.release();
-        tracer->nearBits.release();
-        const int64_t lim = (1 << 20) - 2;
-        bool packable = pv.reach == 1 && !cells.empty();
-        for (const auto& cell : cells)
+int32_t rt_set_probes_from_cameras(rt_tracer* tracer, double cell_size, double keep_radius, uint64_t records_per_probe,
+                                   uint64_t max_store_capacity, uint64_t* probe_count, uint64_t* store_capacity)
+{
+    return guarded([&]() {
+        require(tracer != nullptr, "tracer is null");
+        activate(tracer);
+        // the probe pass of every camera that takes part in the gather (debug cameras, which filter
+        // by bounce or light, do not: reference src/Renderer.cpp:297-371)
+        std::vector<rt_tracer::GatherCache*> caches;
+        uint64_t total = 0;
+        for (size_t c = 0; c < tracer->cameraDesc.size(); ++c)
         {
-            const CellKey& k = cell.first;
-            packable = packable && k.x > -lim && k.x < lim && k.y > -lim && k.y < lim && k.z > -lim && k.z < lim;
+            if (tracer->cameraDesc[c].bounce_filter >= 0 || tracer->cameraDesc[c].light_filter >= 0) continue;
+            rt_tracer::GatherCache& cache = ensureGatherPoints(tracer, static_cast<int32_t>(c));
+            caches.push_back(&cache);
+            total += cache.total;
         }
-        if (packable)
+        require(total < (1ull << 32), "too many probes");
+        DeviceArray<double> positions;
+        positions.allocate(static_cast<size_t>(3 * total));
+        uint64_t at = 0;
+        for (rt_tracer::GatherCache* cache : caches)
         {
-            std::unordered_map<unsigned long long, uint32_t> near;
-            near.reserve(cells.size() * 8);
-            auto pack = [](int64_t x, int64_t y, int64_t z) {
-                const int64_t off = 1 << 20;
-                return (static_cast<unsigned long long>(x + off) << 42) | (static_cast<unsigned long long>(y + off) << 21) |
-                       static_cast<unsigned long long>(z + off);
-            };
-            for (const auto& cell : cells)
-            {
-                const CellKey& k = cell.first;
-                for (int dz = -1; dz <= 1; ++dz)
-                    for (int dy = -1; dy <= 1; ++dy)
-                        for (int dx = -1; dx <= 1; ++dx)
-                        {
-                            // the occupied cell k is the neighbour at (-dx, -dy, -dz) of the cell k + d
-                            const int bit = (1 - dz) * 9 + (1 - dy) * 3 + (1 - dx);
-                            near[pack(k.x + dx, k.y + dy, k.z + dz)] |= 1u << bit;
-                        }
-            }
-            uint64_t nearSlots = 16;
-            while (nearSlots < 2 * near.size() + 1)
-            {
-                nearSlots <<= 1;
-            }
-            std::vector<unsigned long long> nearKey(nearSlots, rtd::kEmptyKey);
-            std::vector<uint32_t> nearBits(nearSlots, 0);
-            const unsigned long long field = (1ull << 21) - 1;
-            for (const auto& entry : near)
-            {
-                const CellKey k{static_cast<int64_t>(entry.first >> 42) - (1 << 20),
-                                static_cast<int64_t>((entry.first >> 21) & field) - (1 << 20),
-                                static_cast<int64_t>(entry.first & field) - (1 << 20)};
-                uint64_t slot = cellSlot(k, nearSlots - 1);
-                while (nearKey[slot] != rtd::kEmptyKey)
-                {
-                    slot = (slot + 1) & (nearSlots - 1);
-                }
-                nearKey[slot] = entry.first;
-                nearBits[slot] = entry.second;
-            }
-            tracer->nearKey.upload(nearKey);
-            tracer->nearBits.upload(nearBits);
-            pv.nearKey = tracer->nearKey.ptr;
-            pv.nearBits = tracer->nearBits.ptr;
-            pv.nearMask = nearSlots - 1;
-    pv.packedCells = tracer->packedCells.ptr;
-    pv.nearEntries = tracer->nearEntries.ptr;
+            rtd::launchProbePositions(cache->devicePoints.ptr, cache->total, positions.ptr + 3 * at, tracer->stream);
+            at += cache->total;
         }
-        tracer->probesSet = true;
+        check(hipGetLastError(), "probe positions launch");
+        // BounceStore sizing, reference src/Renderer.cpp:382-390
+        const uint64_t sized = total == 0 ? max_store_capacity : total * records_per_probe;
+        const uint64_t capacity = std::min<uint64_t>(max_store_capacity, std::max<uint64_t>(1, sized));
+        setProbes(tracer, positions.ptr, true, total, cell_size, keep_radius, capacity);
+        if (probe_count != nullptr) *probe_count = total;
+        if (store_capacity != nullptr) *store_capacity = capacity;
     });
 }
 
@@ -1701,17 +1727,18 @@ int32_t rt_collect_gather_points(rt_tracer* tracer, int32_t camera, double* rows
         require(count != nullptr, "count is null");
         activate(tracer);
         rt_tracer::GatherCache& cache = ensureGatherPoints(tracer, camera);
-        *count = cache.points.size();
+        *count = cache.total;
         if (stats3 != nullptr)
         {
             std::memcpy(stats3, cache.stats, sizeof(cache.stats));
         }
         if (rows19 != nullptr)
         {
-            const uint64_t n = std::min<uint64_t>(capacity, cache.points.size());
+            const std::vector<rtd::GatherPoint>& points = hostGatherPoints(tracer, cache);
+            const uint64_t n = std::min<uint64_t>(capacity, points.size());
             for (uint64_t i = 0; i < n; ++i)
             {
-                const rtd::GatherPoint& g = cache.points[i];
+                const rtd::GatherPoint& g = points[i];
                 double* r = rows19 + 19 * i;
                 r[0] = g.px;
                 r[1] = g.py;
@@ -1828,7 +1855,7 @@ int32_t rt_gather(rt_tracer* tracer, int32_t camera, double gather_cell_size, do
         args.offsets = cache.offsets.ptr;
         args.points = cache.devicePoints.ptr;
         args.stats = stats.ptr;
-        if (!cache.points.empty())
+        if (cache.total > 0)
         {
             rtd::launchGather(args, tracer->stream);
             check(hipGetLastError(), "gather launch");
@@ -1839,7 +1866,7 @@ int32_t rt_gather(rt_tracer* tracer, int32_t camera, double gather_cell_size, do
         check(hipStreamSynchronize(tracer->stream), "hipStreamSynchronize");
         if (stats4 != nullptr)
         {
-            stats4[0] = cache.points.size();  // pixelsHit: every record reached a non-delta surface
+            stats4[0] = cache.total;  // pixelsHit: every record reached a non-delta surface
             stats4[1] = hostStats[0];
             stats4[2] = hostStats[1];
             stats4[3] = n - indexed;

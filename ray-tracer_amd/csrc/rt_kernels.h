@@ -184,6 +184,7 @@ struct ProbeBuild
     uint32_t* order;               // [n] probe index
 };
 void launchProbeKeys(const ProbeBuild& b, uint32_t* unpackable, hipStream_t stream);
+void launchProbePositions(const GatherPoint* points, uint64_t n, double* positions, hipStream_t stream);
 // stable ascending sort of (keys, order) pairs of any length below 2^31
 size_t sortKeyPairs(void* scratch, size_t scratchBytes, const unsigned long long* keysIn, unsigned long long* keysOut,
                     const uint32_t* orderIn, uint32_t* orderOut, uint64_t n, hipStream_t stream);

@@ -1247,6 +1247,16 @@ __global__ __launch_bounds__(256) void gatherKernel(const GatherArgs a)
     }
 }
 
+// positions of a camera's gather points, 3 doubles each: the probes of the keep test
+__global__ void probePositionsKernel(const GatherPoint* points, uint64_t n, double* positions)
+{
+    const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    positions[3 * i + 0] = points[i].position[0];
+    positions[3 * i + 1] = points[i].position[1];
+    positions[3 * i + 2] = points[i].position[2];
+}
+
 // ---------------------------------------------------------------- probe grid build
 // ProbeIndex's constructor (reference src/ProbeIndex.cpp:5-25) hashes every probe into an
 // unordered_map of cells.  Here the probes are keyed by packed cell, sorted, and the runs of
@@ -1558,6 +1568,12 @@ void launchGather(const GatherArgs& args, hipStream_t stream)
 {
     if (args.pixels <= 0) return;
     hipLaunchKernelGGL(gatherKernel, dim3(gridFor(args.pixels)), dim3(256), 0, stream, args);
+}
+
+void launchProbePositions(const GatherPoint* points, uint64_t n, double* positions, hipStream_t stream)
+{
+    if (n == 0) return;
+    hipLaunchKernelGGL(probePositionsKernel, dim3(gridFor(static_cast<int64_t>(n))), dim3(256), 0, stream, points, n, positions);
 }
 
 void launchProbeKeys(const ProbeBuild& b, uint32_t* unpackable, hipStream_t stream)

@@ -218,8 +218,8 @@ RenderResult renderFrame(const LoadedScene& scene, ProgressCallback progress, Pr
     if (settings.useProbeGather)
     {
         // probe pass of every non-debug camera; the union of the record positions is the
-        // keep-test index (reference src/Renderer.cpp:297-371)
-        std::vector<double> probePositions;
+        // keep-test index (reference src/Renderer.cpp:297-371).  Records and index stay on the
+        // device; only the counters come back.
         for (size_t c = 0; c < cameras.size(); ++c)
         {
             if (!cameras[c] || debugCamera[c])
@@ -228,28 +228,17 @@ RenderResult renderFrame(const LoadedScene& scene, ProgressCallback progress, Pr
             }
             uint64_t count = 0, stats[3] = {0, 0, 0};
             check(rt_collect_gather_points(tracer.ptr, static_cast<int32_t>(c), nullptr, 0, &count, stats));
-            std::vector<double> rows(static_cast<size_t>(count) * 19);
-            if (count > 0)
-            {
-                check(rt_collect_gather_points(tracer.ptr, static_cast<int32_t>(c), rows.data(), count, &count, stats));
-            }
-            for (uint64_t i = 0; i < count; ++i)
-            {
-                probePositions.insert(probePositions.end(), {rows[19 * i + 2], rows[19 * i + 3], rows[19 * i + 4]});
-            }
             probeStats[c].cameraRays = stats[0];
             probeStats[c].deltaExtensions = stats[1];
             probeStats[c].misses = stats[2];
         }
-        const size_t probeCount = probePositions.size() / 3;
-        result.probeCount = probeCount;
         probeGatherMinRadius = derived.minSplatRadius;  // reference src/Renderer.cpp:307-310
-        constexpr size_t kSlotsPerProbe = 256;         // :382-390
-        const size_t probeSized = probeCount == 0 ? settings.bounceStoreCapacity : probeCount * kSlotsPerProbe;
-        const size_t capacity = std::min(settings.bounceStoreCapacity, std::max<size_t>(1, probeSized));
+        constexpr uint64_t kSlotsPerProbe = 256;        // :382-390
+        uint64_t probeCount = 0, capacity = 0;
+        check(rt_set_probes_from_cameras(tracer.ptr, derived.keepRadius, derived.keepRadius, kSlotsPerProbe,
+                                         settings.bounceStoreCapacity, &probeCount, &capacity));
+        result.probeCount = probeCount;
         result.bounceStoreCapacity = capacity;
-        check(rt_set_probes(tracer.ptr, probePositions.data(), probeCount, derived.keepRadius, derived.keepRadius,
-                            capacity));
         check(rt_reset(tracer.ptr));
         // emitter deposits go in first so an overflow can never drop them (:394-418)
         const double emitterGatherCell =

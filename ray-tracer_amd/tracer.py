@@ -40,6 +40,8 @@ _SIGNATURES = {
     "rt_destroy": (None, [C.c_void_p]),
     "rt_set_stream": (C.c_int32, [C.c_void_p, C.c_void_p]),
     "rt_set_probes": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_double, C.c_double, C.c_uint64]),
+    "rt_set_probes_from_cameras": (C.c_int32, [C.c_void_p, C.c_double, C.c_double, C.c_uint64, C.c_uint64,
+                                                C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "rt_set_splat": (C.c_int32, [C.c_void_p, C.c_double, C.c_double, C.c_uint64]),
     "rt_bind_camera_buffer": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p]),
     "rt_reset": (C.c_int32, [C.c_void_p]),
@@ -152,6 +154,14 @@ class Tracer:
         probes = np.ascontiguousarray(probes, dtype=np.float64).reshape(-1, 3)
         _check(tracer_lib().rt_set_probes(self._handle, _ptr(probes), probes.shape[0], cell_size, keep_radius,
                                           store_capacity))
+
+    def set_probes_from_cameras(self, cell_size, keep_radius, records_per_probe=256, max_store_capacity=40_000_000):
+        """Probes = the probe-pass records of the gathering cameras, kept on the device.  Returns
+        (probe count, store capacity)."""
+        probes, capacity = C.c_uint64(), C.c_uint64()
+        _check(tracer_lib().rt_set_probes_from_cameras(self._handle, cell_size, keep_radius, records_per_probe,
+                                                       max_store_capacity, C.byref(probes), C.byref(capacity)))
+        return int(probes.value), int(capacity.value)
 
     def set_splat(self, min_splat_radius, density_cell_size=0.0, density_capacity=1 << 20):
         _check(tracer_lib().rt_set_splat(self._handle, min_splat_radius, density_cell_size, density_capacity))

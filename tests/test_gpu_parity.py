@@ -325,6 +325,33 @@ def test_probe_pass_equals_reference_where_rng_free(rt, golden, manifest, scene_
     assert_bits_equal(direct_got, direct_want, "RNG-free gather points vs reference")
 
 
+@pytest.mark.parametrize("name", ["mixed", "multicam", "animated"])
+def test_probes_from_cameras_equal_probes_through_the_host(rt, scene_opener, name):
+    """rt_set_probes_from_cameras builds the keep-test index from the probe-pass records on the
+    device; the photon pass then keeps exactly what it keeps with the same positions handed over
+    by the caller, and the store is sized by the reference's rule."""
+    entry = dict(PROBE_SCENES[name], photons_per_light=4000)
+    scene, tracer, orc = _open(rt, scene_opener, entry)
+    setup = O.frame_setup(orc, O.RNG_COUNTER, O.MATH_PORTABLE)
+    keep = setup["keep_radius"]
+    probes = tracer.collect_probe_positions()
+    tracer.set_probes(probes, keep, keep, setup["store_capacity"])
+    tracer.reset()
+    tracer.trace(sink_mode=1)
+    want_counters, want_store = tracer.counters(), _sorted_records(tracer.store())
+
+    other = rt.Tracer(scene)
+    count, capacity = other.set_probes_from_cameras(keep, keep, 256, int(scene.settings.bounce_store_capacity))
+    assert count == probes.shape[0] and capacity == setup["store_capacity"]
+    other.reset()
+    other.trace(sink_mode=1)
+    got = other.counters()
+    for k in ("kept", "culled", "store_size", "deposits"):
+        assert got[k] == want_counters[k], k
+    assert want_counters["kept"] > 0
+    assert_bits_equal(_sorted_records(other.store()), want_store, "store records")
+
+
 def test_probe_keep_test_matches_store_decisions(rt, scene_opener):
     """rt_probe_keep_test gives, for points handed over from the host, the same decision the
     photon pass takes for its own deposits."""
