@@ -129,6 +129,14 @@ int32_t rt_set_probes(rt_tracer* tracer, const double* probes, uint64_t n, doubl
 int32_t rt_set_probes_from_cameras(rt_tracer* tracer, double cell_size, double keep_radius, uint64_t records_per_probe,
                                    uint64_t max_store_capacity, uint64_t* probe_count, uint64_t* store_capacity);
 
+/* ProbeGather::depositEmitters (reference src/ProbeGather.cpp:464-550) on the device: the lit
+ * face of every area light is tiled with cell-centred deposits `deposit_spacing` apart, those
+ * within the keep radius of a probe are appended to the store as timeless records carrying the
+ * patch's power share.  Call after rt_set_probes* and rt_reset and before rt_trace, so that a
+ * store overflow can never drop them (reference src/Renderer.cpp:394-418).  *samples = deposits
+ * generated, *kept = deposits that passed the keep test (either may be NULL). */
+int32_t rt_deposit_emitters(rt_tracer* tracer, double deposit_spacing, uint64_t* samples, uint64_t* kept);
+
 /* Sink B set-up: Worker::setMinSplatRadius / setSplatTargets / the DensityGrid
  * (reference src/Renderer.cpp:196-274,445-457).  density_cell_size <= 0 disables the
  * grid; density_capacity is the number of hash slots reserved for occupied cells. */

@@ -188,6 +188,7 @@ struct rt_tracer
 
     // probe pass
     DeviceArray<rtd::EmitterPatch> patches;
+    std::vector<rtd::EmitterPatch> patchHost;
     struct GatherCache  // one camera's probe pass, kept on the device for the gather
     {
         bool valid = false;
@@ -592,6 +593,7 @@ void buildScene(rt_tracer* t, const rt_scene* scene)
         patches.push_back(patch);
     }
     t->patches.upload(patches);
+    t->patchHost = patches;
     t->gatherCache.clear();
     for (int64_t i = 0; i < scene->camera_count; ++i)
     {
@@ -713,22 +715,29 @@ rt_tracer::GatherCache& ensureGatherPoints(rt_tracer* tracer, int32_t camera)
     stats.zero(tracer->stream);
     rtd::launchGatherCount(tracer->view, camera, stride, pixels, cache.counts.ptr, stats.ptr, tracer->stream);
     check(hipGetLastError(), "gather count launch");
-    std::vector<uint32_t> hostCounts(static_cast<size_t>(pixels));
-    check(hipMemcpyAsync(hostCounts.data(), cache.counts.ptr, hostCounts.size() * sizeof(uint32_t),
-                         hipMemcpyDeviceToHost, tracer->stream),
-          "hipMemcpyAsync counts");
+    // offsets of every pixel's records: exclusive scan of the counts, on the device
+    cache.offsets.allocate(static_cast<size_t>(pixels));
+    size_t scanBytes = rtd::scanCounts(nullptr, 0, cache.counts.ptr, cache.offsets.ptr, pixels, tracer->stream);
+    DeviceArray<unsigned char> scanScratch;
+    scanScratch.allocate(std::max<size_t>(scanBytes, 1));
+    rtd::scanCounts(scanScratch.ptr, scanBytes, cache.counts.ptr, cache.offsets.ptr, pixels, tracer->stream);
+    check(hipGetLastError(), "gather offsets scan");
     unsigned long long hostStats[3] = {0, 0, 0};
     check(hipMemcpyAsync(hostStats, stats.ptr, sizeof(hostStats), hipMemcpyDeviceToHost, tracer->stream),
           "hipMemcpyAsync stats");
-    check(hipStreamSynchronize(tracer->stream), "hipStreamSynchronize");
-    std::vector<uint64_t> hostOffsets(hostCounts.size());
-    uint64_t total = 0;
-    for (size_t i = 0; i < hostCounts.size(); ++i)
+    uint64_t lastOffset = 0;
+    uint32_t lastCount = 0;
+    if (pixels > 0)
     {
-        hostOffsets[i] = total;
-        total += hostCounts[i];
+        check(hipMemcpyAsync(&lastOffset, cache.offsets.ptr + (pixels - 1), sizeof(lastOffset), hipMemcpyDeviceToHost,
+                             tracer->stream),
+              "hipMemcpyAsync last offset");
+        check(hipMemcpyAsync(&lastCount, cache.counts.ptr + (pixels - 1), sizeof(lastCount), hipMemcpyDeviceToHost,
+                             tracer->stream),
+              "hipMemcpyAsync last count");
     }
-    cache.offsets.upload(hostOffsets);
+    check(hipStreamSynchronize(tracer->stream), "hipStreamSynchronize");
+    const uint64_t total = lastOffset + lastCount;
     cache.total = total;
     cache.points.clear();
     cache.hostCopied = false;
@@ -1311,6 +1320,83 @@ int32_t rt_set_probes_from_cameras(rt_tracer* tracer, double cell_size, double k
         setProbes(tracer, positions.ptr, true, total, cell_size, keep_radius, capacity);
         if (probe_count != nullptr) *probe_count = total;
         if (store_capacity != nullptr) *store_capacity = capacity;
+    });
+}
+
+int32_t rt_deposit_emitters(rt_tracer* tracer, double deposit_spacing, uint64_t* samples, uint64_t* kept)
+{
+    return guarded([&]() {
+        require(tracer != nullptr, "tracer is null");
+        if (!tracer->probesSet)
+        {
+            throw ApiError(RT_ERR_STATE, "rt_deposit_emitters needs the probes (rt_set_probes) first");
+        }
+        activate(tracer);
+        hipStream_t stream = tracer->stream;
+        DeviceArray<unsigned long long> scalars;  // [0] samples on the patch, [1] kept
+        scalars.allocate(2);
+        const double spacing = std::max(deposit_spacing, 1e-6);
+        rtd::StoreView store{tracer->storeRecords.ptr, tracer->scalars.ptr + 1, tracer->storeCapacity};
+        uint64_t sampleTotal = 0, keptTotal = 0;
+        for (const rtd::EmitterPatch& patch : tracer->patchHost)
+        {
+            const double extentU = patch.isDisc ? patch.radius : patch.halfWidth;
+            const double extentV = patch.isDisc ? patch.radius : patch.halfHeight;
+            if (extentU <= 0.0 || extentV <= 0.0)
+            {
+                continue;
+            }
+            rtd::EmitterGrid grid{};
+            const double cellsU = std::ceil(2.0 * extentU / spacing), cellsV = std::ceil(2.0 * extentV / spacing);
+            require(cellsU < 2147483647.0 && cellsV < 2147483647.0, "emitter deposit grid too fine");
+            grid.countU = std::max(1, static_cast<int>(cellsU));
+            grid.countV = std::max(1, static_cast<int>(cellsV));
+            grid.stepU = (2.0 * extentU) / grid.countU;
+            grid.stepV = (2.0 * extentV) / grid.countV;
+            grid.extentU = extentU;
+            grid.extentV = extentV;
+            grid.radius = patch.radius;
+            grid.isDisc = patch.isDisc;
+            std::memcpy(grid.center, patch.center, sizeof(grid.center));
+            std::memcpy(grid.right, patch.right, sizeof(grid.right));
+            std::memcpy(grid.up, patch.up, sizeof(grid.up));
+            for (int k = 0; k < 3; ++k)
+            {
+                grid.normal[k] = static_cast<float>(patch.normal[k]);
+            }
+            const double area = patch.isDisc ? (M_PI * patch.radius * patch.radius)
+                                             : (2.0 * patch.halfWidth) * (2.0 * patch.halfHeight);
+            // the deposits share the patch's power: their number comes first
+            uint64_t count = static_cast<uint64_t>(grid.countU) * static_cast<uint64_t>(grid.countV);
+            if (patch.isDisc)
+            {
+                scalars.zero(stream);
+                rtd::launchEmitterCount(grid, scalars.ptr, stream);
+                unsigned long long inside = 0;
+                check(hipMemcpyAsync(&inside, scalars.ptr, sizeof(inside), hipMemcpyDeviceToHost, stream), "hipMemcpyAsync");
+                check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+                count = inside;
+            }
+            if (count == 0)
+            {
+                continue;
+            }
+            sampleTotal += count;
+            const double perDepositScale = (M_PI * area) / (4.0 * static_cast<double>(count));
+            for (int k = 0; k < 3; ++k)
+            {
+                grid.power[k] = patch.radiance[k] * static_cast<float>(perDepositScale);
+            }
+            scalars.zero(stream);
+            rtd::launchEmitterDeposit(grid, tracer->probeView, store, scalars.ptr + 1, stream);
+            check(hipGetLastError(), "emitter deposit launch");
+            unsigned long long keptHere = 0;
+            check(hipMemcpyAsync(&keptHere, scalars.ptr + 1, sizeof(keptHere), hipMemcpyDeviceToHost, stream), "hipMemcpyAsync");
+            check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+            keptTotal += keptHere;
+        }
+        if (samples != nullptr) *samples = sampleTotal;
+        if (kept != nullptr) *kept = keptTotal;
     });
 }
 

@@ -184,6 +184,22 @@ struct ProbeBuild
     uint32_t* order;               // [n] probe index
 };
 void launchProbeKeys(const ProbeBuild& b, uint32_t* unpackable, hipStream_t stream);
+// offsets[i] = counts[0] + ... + counts[i - 1] (returns the scratch bytes needed when scratch is null)
+size_t scanCounts(void* scratch, size_t scratchBytes, const uint32_t* counts, uint64_t* offsets, int64_t n, hipStream_t stream);
+// ProbeGather::depositEmitters for one emitter patch: a countU x countV grid of cell-centred
+// samples over the patch (inside the disc for a disc).
+struct EmitterGrid
+{
+    double center[3], right[3], up[3];
+    float normal[3], power[3];
+    double extentU, extentV, stepU, stepV, radius;
+    int32_t countU, countV, isDisc;
+};
+// number of samples of the grid that lie on the patch (adds to *count)
+void launchEmitterCount(const EmitterGrid& grid, unsigned long long* count, hipStream_t stream);
+// appends the samples that pass the keep test to the store (adds their number to *kept)
+void launchEmitterDeposit(const EmitterGrid& grid, const ProbeView& probes, const StoreView& store,
+                          unsigned long long* kept, hipStream_t stream);
 void launchProbePositions(const GatherPoint* points, uint64_t n, double* positions, hipStream_t stream);
 // stable ascending sort of (keys, order) pairs of any length below 2^31
 size_t sortKeyPairs(void* scratch, size_t scratchBytes, const unsigned long long* keysIn, unsigned long long* keysOut,

@@ -13,6 +13,7 @@
 
 #include "rt_kernels.h"
 
+#include <algorithm>
 #include <cstdio>
 
 #include <hipcub/hipcub.hpp>
@@ -1247,6 +1248,59 @@ __global__ __launch_bounds__(256) void gatherKernel(const GatherArgs a)
     }
 }
 
+// ---------------------------------------------------------------- emitter deposits
+// ProbeGather::depositEmitters, reference src/ProbeGather.cpp:464-550: sample (iu, iv) of a
+// patch's grid, or no sample when it falls outside a disc.  The arithmetic is the reference's.
+RT_DEV bool emitterSample(const EmitterGrid& g, long long index, Vec* position)
+{
+    const int iu = static_cast<int>(index / g.countV), iv = static_cast<int>(index % g.countV);
+    const double u = -g.extentU + (iu + 0.5) * g.stepU;
+    const double v = -g.extentV + (iv + 0.5) * g.stepV;
+    if (g.isDisc && (u * u + v * v) > (g.radius * g.radius))
+    {
+        return false;
+    }
+    const Vec center = mk(g.center[0], g.center[1], g.center[2]);
+    const Vec right = mk(g.right[0], g.right[1], g.right[2]), up = mk(g.up[0], g.up[1], g.up[2]);
+    *position = center + right * u + up * v;
+    return true;
+}
+
+__global__ void emitterCountKernel(const EmitterGrid g, unsigned long long* count)
+{
+    const long long total = static_cast<long long>(g.countU) * g.countV;
+    unsigned long long mine = 0;
+    for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < total;
+         i += static_cast<long long>(gridDim.x) * blockDim.x)
+    {
+        Vec p;
+        if (emitterSample(g, i, &p)) mine += 1;
+    }
+    mine = waveSum(mine);
+    if ((threadIdx.x & 63) == 0 && mine != 0) atomicAdd(count, mine);
+}
+
+__global__ void emitterDepositKernel(const EmitterGrid g, const ProbeView probes, const StoreView store,
+                                     unsigned long long* kept)
+{
+    const long long total = static_cast<long long>(g.countU) * g.countV;
+    const long long stride = static_cast<long long>(gridDim.x) * blockDim.x;
+    const long long rounds = (total + stride - 1) / stride;
+    unsigned long long mine = 0;
+    for (long long round = 0; round < rounds; ++round)  // whole waves stay together for the append
+    {
+        const long long i = round * stride + static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+        Vec p = mk(0, 0, 0);
+        const bool keep = i < total && emitterSample(g, i, &p) && anyProbeWithin(probes, p);
+        const Vec n = mk(g.normal[0], g.normal[1], g.normal[2]);
+        // incoming direction = normal, time = +inf: a timeless deposit (reference :528-541)
+        storeAppend(store, keep, p, n, n, __builtin_inff(), Color{g.power[0], g.power[1], g.power[2]});
+        if (keep) mine += 1;
+    }
+    mine = waveSum(mine);
+    if ((threadIdx.x & 63) == 0 && mine != 0) atomicAdd(kept, mine);
+}
+
 // positions of a camera's gather points, 3 doubles each: the probes of the keep test
 __global__ void probePositionsKernel(const GatherPoint* points, uint64_t n, double* positions)
 {
@@ -1286,16 +1340,29 @@ __global__ void probeKeysKernel(const ProbeBuild b, uint32_t* unpackable)
     b.order[i] = static_cast<uint32_t>(i);
 }
 
-// runs[0] += number of runs of equal keys (= occupied cells)
+// runs[0] += number of runs of equal keys (= occupied cells); a block counts 16 keys per
+// thread and adds once, so that the one counter sees a few thousand atomics, not millions
+constexpr int kRunsPerThread = 16;
 __global__ void countRunsKernel(const unsigned long long* keys, uint64_t n, unsigned long long* runs)
 {
-    const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    const bool head = i < n && (i == 0 || keys[i] != keys[i - 1]);
-    const unsigned long long mask = __ballot(head);
-    if ((threadIdx.x & 63) == 0 && mask != 0)
+    __shared__ unsigned int blockHeads;
+    if (threadIdx.x == 0) blockHeads = 0;
+    __syncthreads();
+    const uint64_t blockBase = static_cast<uint64_t>(blockIdx.x) * blockDim.x * kRunsPerThread;
+    unsigned int heads = 0;
+    for (int k = 0; k < kRunsPerThread; ++k)
     {
-        atomicAdd(runs, static_cast<unsigned long long>(__builtin_popcountll(mask)));
+        const uint64_t i = blockBase + static_cast<uint64_t>(k) * blockDim.x + threadIdx.x;
+        if (i < n && (i == 0 || keys[i] != keys[i - 1])) heads += 1;
     }
+#pragma unroll
+    for (int offset = 32; offset > 0; offset >>= 1)
+    {
+        heads += __shfl_down(heads, offset, 64);
+    }
+    if ((threadIdx.x & 63) == 0 && heads != 0) atomicAdd(&blockHeads, heads);
+    __syncthreads();
+    if (threadIdx.x == 0 && blockHeads != 0) atomicAdd(runs, static_cast<unsigned long long>(blockHeads));
 }
 
 // every probe is copied to its place in cell order; the first probe of every cell enters the
@@ -1564,10 +1631,41 @@ size_t sortStoreKeys(void* scratch, size_t scratchBytes, const unsigned long lon
     return bytes;
 }
 
+namespace
+{
+struct WidenCount
+{
+    __host__ __device__ uint64_t operator()(uint32_t v) const { return static_cast<uint64_t>(v); }
+};
+}  // namespace
+
+size_t scanCounts(void* scratch, size_t scratchBytes, const uint32_t* counts, uint64_t* offsets, int64_t n, hipStream_t stream)
+{
+    size_t bytes = scratchBytes;
+    hipcub::TransformInputIterator<uint64_t, WidenCount, const uint32_t*> wide(counts, WidenCount());
+    (void)hipcub::DeviceScan::ExclusiveSum(scratch, bytes, wide, offsets, static_cast<int>(n), stream);
+    return bytes;
+}
+
 void launchGather(const GatherArgs& args, hipStream_t stream)
 {
     if (args.pixels <= 0) return;
     hipLaunchKernelGGL(gatherKernel, dim3(gridFor(args.pixels)), dim3(256), 0, stream, args);
+}
+
+void launchEmitterCount(const EmitterGrid& grid, unsigned long long* count, hipStream_t stream)
+{
+    const long long total = static_cast<long long>(grid.countU) * grid.countV;
+    const int blocks = static_cast<int>(std::min<long long>(4096, (total + 255) / 256));
+    hipLaunchKernelGGL(emitterCountKernel, dim3(blocks), dim3(256), 0, stream, grid, count);
+}
+
+void launchEmitterDeposit(const EmitterGrid& grid, const ProbeView& probes, const StoreView& store,
+                          unsigned long long* kept, hipStream_t stream)
+{
+    const long long total = static_cast<long long>(grid.countU) * grid.countV;
+    const int blocks = static_cast<int>(std::min<long long>(4096, (total + 255) / 256));
+    hipLaunchKernelGGL(emitterDepositKernel, dim3(blocks), dim3(256), 0, stream, grid, probes, store, kept);
 }
 
 void launchProbePositions(const GatherPoint* points, uint64_t n, double* positions, hipStream_t stream)
@@ -1594,7 +1692,8 @@ size_t sortKeyPairs(void* scratch, size_t scratchBytes, const unsigned long long
 void launchCountRuns(const unsigned long long* sortedKeys, uint64_t n, unsigned long long* runs, hipStream_t stream)
 {
     if (n == 0) return;
-    hipLaunchKernelGGL(countRunsKernel, dim3(gridFor(static_cast<int64_t>(n))), dim3(256), 0, stream, sortedKeys, n, runs);
+    hipLaunchKernelGGL(countRunsKernel, dim3(gridFor(static_cast<int64_t>((n + kRunsPerThread - 1) / kRunsPerThread))), dim3(256),
+                       0, stream, sortedKeys, n, runs);
 }
 
 void launchProbeTable(const unsigned long long* sortedKeys, const uint32_t* sortedOrder, const double* points, uint64_t n,

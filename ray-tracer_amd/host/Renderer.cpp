@@ -6,6 +6,8 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cmath>
 #include <cstring>
 #include <future>
@@ -34,126 +36,6 @@ struct TracerHandle
         if (ptr) rt_destroy(ptr);
     }
 };
-
-// One emitter patch: the lit face of an area light (reference src/EmitterPatch.cpp:15-53,
-// AreaLight::surfaceRadiance src/AreaLight.cpp:80-104), from the flattened light.
-struct Patch
-{
-    Vector center, right, up, normal;
-    Color radiance;
-    double halfWidth = 0.0, halfHeight = 0.0, radius = 0.0;
-    bool isDisc = false;
-};
-
-std::vector<Patch> collectEmitterPatches(const rt_scene& scene)
-{
-    std::vector<Patch> patches;
-    for (int64_t i = 0; i < scene.light_count; ++i)
-    {
-        const rt_light& l = scene.lights[i];
-        if (l.type != RT_LIGHT_AREA)
-        {
-            continue;
-        }
-        const double area = l.shape == 1 ? Utility::pi * l.radius * l.radius : l.width * l.height;
-        Color radiance;
-        if (area > 0.0)
-        {
-            const double exitance = l.luminous_flux / area;
-            radiance = Color{l.color[0], l.color[1], l.color[2]} * static_cast<float>(exitance / Utility::pi);
-        }
-        if (radiance.red <= 0.0f && radiance.green <= 0.0f && radiance.blue <= 0.0f)
-        {
-            continue;
-        }
-        const Quaternion q{l.rotation[0], l.rotation[1], l.rotation[2], l.rotation[3]};
-        Patch p;
-        p.center = Vector{l.position[0], l.position[1], l.position[2]};
-        p.right = (q * Vector{1.0, 0.0, 0.0}).normalized();
-        p.up = (q * Vector{0.0, 1.0, 0.0}).normalized();
-        p.normal = (q * Vector{0.0, 0.0, 1.0}).normalized();
-        p.radiance = radiance;
-        if (l.shape == 1)
-        {
-            p.isDisc = true;
-            p.radius = l.radius;
-        }
-        else
-        {
-            p.halfWidth = l.width * 0.5;
-            p.halfHeight = l.height * 0.5;
-        }
-        patches.push_back(p);
-    }
-    return patches;
-}
-
-// ProbeGather::depositEmitters (reference src/ProbeGather.cpp:464-550): tile every patch
-// with cell-centred deposits, keep those near a probe (device keep-test), append them to
-// the store ahead of the photon pass.  Returns the number kept.
-size_t depositEmitters(rt_tracer* tracer, const rt_scene& scene, double depositSpacing)
-{
-    const std::vector<Patch> patches = collectEmitterPatches(scene);
-    const double spacing = std::max(depositSpacing, 1e-6);
-    size_t keptTotal = 0;
-    for (const Patch& patch : patches)
-    {
-        const double extentU = patch.isDisc ? patch.radius : patch.halfWidth;
-        const double extentV = patch.isDisc ? patch.radius : patch.halfHeight;
-        if (extentU <= 0.0 || extentV <= 0.0)
-        {
-            continue;
-        }
-        const int countU = std::max(1, static_cast<int>(std::ceil(2.0 * extentU / spacing)));
-        const int countV = std::max(1, static_cast<int>(std::ceil(2.0 * extentV / spacing)));
-        const double stepU = (2.0 * extentU) / countU;
-        const double stepV = (2.0 * extentV) / countV;
-        const double area = patch.isDisc ? (Utility::pi * patch.radius * patch.radius)
-                                         : (2.0 * patch.halfWidth) * (2.0 * patch.halfHeight);
-        std::vector<double> samples;
-        for (int iu = 0; iu < countU; ++iu)
-        {
-            const double u = -extentU + (iu + 0.5) * stepU;
-            for (int iv = 0; iv < countV; ++iv)
-            {
-                const double v = -extentV + (iv + 0.5) * stepV;
-                if (patch.isDisc && (u * u + v * v) > (patch.radius * patch.radius))
-                {
-                    continue;
-                }
-                const Vector p = patch.center + patch.right * u + patch.up * v;
-                samples.insert(samples.end(), {p.x, p.y, p.z});
-            }
-        }
-        const size_t count = samples.size() / 3;
-        if (count == 0)
-        {
-            continue;
-        }
-        const double perDepositScale = (Utility::pi * area) / (4.0 * static_cast<double>(count));
-        const Color power = patch.radiance * static_cast<float>(perDepositScale);
-        std::vector<uint8_t> keep(count, 0);
-        check(rt_probe_keep_test(tracer, static_cast<int64_t>(count), samples.data(), keep.data()));
-        std::vector<float> records;
-        for (size_t i = 0; i < count; ++i)
-        {
-            if (!keep[i])
-            {
-                continue;
-            }
-            const float n[3] = {static_cast<float>(patch.normal.x), static_cast<float>(patch.normal.y),
-                                static_cast<float>(patch.normal.z)};
-            records.insert(records.end(),
-                           {static_cast<float>(samples[3 * i]), static_cast<float>(samples[3 * i + 1]),
-                            static_cast<float>(samples[3 * i + 2]), n[0], n[1], n[2], n[0], n[1], n[2],
-                            std::numeric_limits<float>::infinity(), power.red, power.green, power.blue});
-        }
-        const size_t kept = records.size() / 13;
-        check(rt_store_append(tracer, records.data(), kept));
-        keptTotal += kept;
-    }
-    return keptTotal;
-}
 
 }  // namespace
 
@@ -204,8 +86,21 @@ RenderResult renderFrame(const LoadedScene& scene, ProgressCallback progress, Pr
     const FrameDerived derived = deriveFrame(flat.scene);
 
     const auto photonPassStart = std::chrono::steady_clock::now();
+    // RT_AMD_VERBOSE=1: wall time of every stage of the frame on stderr
+    const bool verbose = std::getenv("RT_AMD_VERBOSE") != nullptr;
+    auto stageStart = photonPassStart;
+    auto stage = [&](const char* name) {
+        if (verbose)
+        {
+            const auto now = std::chrono::steady_clock::now();
+            std::fprintf(stderr, "[rt_amd] %-28s %8.1f ms\n", name,
+                         std::chrono::duration<double, std::milli>(now - stageStart).count());
+            stageStart = now;
+        }
+    };
     TracerHandle tracer;
     check(rt_create(&flat.scene, g_device, &tracer.ptr));
+    stage("rt_create");
 
     std::vector<bool> debugCamera(cameras.size(), false);
     for (size_t c = 0; c < cameras.size(); ++c)
@@ -232,6 +127,7 @@ RenderResult renderFrame(const LoadedScene& scene, ProgressCallback progress, Pr
             probeStats[c].deltaExtensions = stats[1];
             probeStats[c].misses = stats[2];
         }
+        stage("probe pass");
         probeGatherMinRadius = derived.minSplatRadius;  // reference src/Renderer.cpp:307-310
         constexpr uint64_t kSlotsPerProbe = 256;        // :382-390
         uint64_t probeCount = 0, capacity = 0;
@@ -239,11 +135,15 @@ RenderResult renderFrame(const LoadedScene& scene, ProgressCallback progress, Pr
                                          settings.bounceStoreCapacity, &probeCount, &capacity));
         result.probeCount = probeCount;
         result.bounceStoreCapacity = capacity;
+        stage("probe index and store");
         check(rt_reset(tracer.ptr));
         // emitter deposits go in first so an overflow can never drop them (:394-418)
         const double emitterGatherCell =
             derived.sceneDepthFootprint > 0.0 ? derived.sceneDepthFootprint : derived.cellSize;
-        result.emitterDepositsKept = depositEmitters(tracer.ptr, flat.scene, std::max(emitterGatherCell * 0.5, 1e-6));
+        uint64_t emitterSamples = 0, emitterKept = 0;
+        check(rt_deposit_emitters(tracer.ptr, std::max(emitterGatherCell * 0.5, 1e-6), &emitterSamples, &emitterKept));
+        result.emitterDepositsKept = emitterKept;
+        stage("emitter deposits");
     }
     else
     {
@@ -277,6 +177,7 @@ RenderResult renderFrame(const LoadedScene& scene, ProgressCallback progress, Pr
     }
     rt_counters counters{};
     check(rt_read_counters(tracer.ptr, &counters));
+    stage("photon pass (sort + trace)");
     result.photonPassSeconds =
         std::chrono::duration<double>(std::chrono::steady_clock::now() - photonPassStart).count();
     result.photons = counters.photons;

@@ -42,6 +42,7 @@ _SIGNATURES = {
     "rt_set_probes": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_double, C.c_double, C.c_uint64]),
     "rt_set_probes_from_cameras": (C.c_int32, [C.c_void_p, C.c_double, C.c_double, C.c_uint64, C.c_uint64,
                                                 C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "rt_deposit_emitters": (C.c_int32, [C.c_void_p, C.c_double, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "rt_set_splat": (C.c_int32, [C.c_void_p, C.c_double, C.c_double, C.c_uint64]),
     "rt_bind_camera_buffer": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p]),
     "rt_reset": (C.c_int32, [C.c_void_p]),
@@ -162,6 +163,12 @@ class Tracer:
         _check(tracer_lib().rt_set_probes_from_cameras(self._handle, cell_size, keep_radius, records_per_probe,
                                                        max_store_capacity, C.byref(probes), C.byref(capacity)))
         return int(probes.value), int(capacity.value)
+
+    def deposit_emitters(self, deposit_spacing):
+        """Emitter-face deposits straight into the store; returns (generated, kept)."""
+        samples, kept = C.c_uint64(), C.c_uint64()
+        _check(tracer_lib().rt_deposit_emitters(self._handle, deposit_spacing, C.byref(samples), C.byref(kept)))
+        return int(samples.value), int(kept.value)
 
     def set_splat(self, min_splat_radius, density_cell_size=0.0, density_capacity=1 << 20):
         _check(tracer_lib().rt_set_splat(self._handle, min_splat_radius, density_cell_size, density_capacity))

@@ -352,6 +352,22 @@ def test_probes_from_cameras_equal_probes_through_the_host(rt, scene_opener, nam
     assert_bits_equal(_sorted_records(other.store()), want_store, "store records")
 
 
+@pytest.mark.parametrize("name", ["mixed", "cbgmd", "animated"])
+def test_emitter_deposits_equal_oracle(rt, scene_opener, name):
+    """rt_deposit_emitters tiles the lit faces on the device: the same records as the oracle's
+    ProbeGather::depositEmitters (as a multiset: the device appends in no particular order)."""
+    scene, tracer, orc = _open(rt, scene_opener, GATHER_SCENES[name])
+    setup = O.frame_setup(orc, O.RNG_COUNTER, O.MATH_PORTABLE)
+    keep = setup["keep_radius"]
+    want, stats = orc.deposit_emitters(setup["probes"], keep, keep, setup["emitter_spacing"])
+    tracer.set_probes_from_cameras(keep, keep, 256, int(scene.settings.bounce_store_capacity))
+    tracer.reset()
+    samples, kept = tracer.deposit_emitters(setup["emitter_spacing"])
+    assert kept == len(want) and kept > 0 and samples == stats["generated"]
+    assert tracer.counters()["store_size"] == kept
+    assert_bits_equal(_sorted_records(tracer.store()), _sorted_records(np.asarray(want)), "emitter deposits")
+
+
 def test_probe_keep_test_matches_store_decisions(rt, scene_opener):
     """rt_probe_keep_test gives, for points handed over from the host, the same decision the
     photon pass takes for its own deposits."""
