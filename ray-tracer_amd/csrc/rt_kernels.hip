@@ -246,8 +246,7 @@ RT_DEV void storeAppend(const StoreView& sv, bool keep, const Vec& position, con
 }
 
 // DensityGrid::add, reference src/DensityGrid.cpp:25-34.
-RT_DEV void densityAdd(const DensityView& dv, const Vec& p, const Color& power, unsigned long long& newCells,
-                       unsigned long long& overflow)
+RT_DEV void densityAdd(const DensityView& dv, const Vec& p, const Color& power, uint32_t& newCells, uint32_t& overflow)
 {
     const int64_t cx = static_cast<int64_t>(__builtin_floor(p.x * dv.invCellSize));
     const int64_t cy = static_cast<int64_t>(__builtin_floor(p.y * dv.invCellSize));
@@ -265,7 +264,10 @@ RT_DEV void densityAdd(const DensityView& dv, const Vec& p, const Color& power, 
     h ^= static_cast<uint64_t>(cy) * 19349663ull;
     h ^= static_cast<uint64_t>(cz) * 83492791ull;
     uint64_t slot = (h * 0x9E3779B97F4A7C15ull) >> 20 & dv.slotMask;
-    for (uint64_t tries = 0; tries <= dv.slotMask; ++tries)
+    // a table that is (nearly) full must not turn every deposit into a walk over all of it: after
+    // this many occupied slots in a row the deposit counts as overflow
+    constexpr uint64_t kMostProbes = 512;
+    for (uint64_t tries = 0; tries <= dv.slotMask && tries < kMostProbes; ++tries)
     {
         const unsigned long long seen = atomicCAS(dv.keys + slot, kEmptyKey, key);
         if (seen == kEmptyKey || seen == key)
@@ -285,11 +287,13 @@ RT_DEV void densityAdd(const DensityView& dv, const Vec& p, const Color& power, 
     overflow += 1;
 }
 
+// Per-lane tallies of one launch, summed per wave at its end.  32 bits each: a lane sees
+// (photons of the launch / lanes of the grid) x bounces events, far below 2^32.
 struct LocalCounters
 {
-    unsigned long long photons = 0, casts = 0, bounces = 0, deposits = 0, kept = 0, culled = 0;
-    unsigned long long splatTotal = 0, splatRadiusClamped = 0, splatLuminanceClamped = 0;
-    unsigned long long densityCells = 0, densityDeposits = 0, densityOverflow = 0;
+    uint32_t photons = 0, casts = 0, bounces = 0, deposits = 0, kept = 0, culled = 0;
+    uint32_t splatTotal = 0, splatRadiusClamped = 0, splatLuminanceClamped = 0;
+    uint32_t densityCells = 0, densityDeposits = 0, densityOverflow = 0;
     double power[3] = {0.0, 0.0, 0.0};
 };
 
@@ -720,8 +724,8 @@ __global__ __launch_bounds__(kTraceThreads) void traceKernel(const TraceArgs a)
                     a.records.castsValid[2 * recordSlot + 1] = valid;
                 }
                 lc.photons += 1;
-                lc.casts += static_cast<unsigned long long>(casts);
-                lc.bounces += static_cast<unsigned long long>(valid);
+                lc.casts += static_cast<uint32_t>(casts);
+                lc.bounces += static_cast<uint32_t>(valid);
                 alive = false;
             }
         }

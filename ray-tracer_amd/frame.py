@@ -26,7 +26,10 @@ def prepare_sinks(rt, scene, tracer, sink):
     d = derive(rt, scene)
     info = dict(d)
     if sink == "splat":
-        tracer.set_splat(d["min_splat_radius"], d["cell_size"], 1 << 22)
+        # the reference's DensityGrid grows without bound; size ours for one cell per deposit, 4 Mi .. 128 Mi cells
+        bound = int(scene.settings.photons_per_light) * max(1, int(scene.desc.light_count)) * (
+            max(0, int(scene.settings.bounce_threshold)) + 1)
+        tracer.set_splat(d["min_splat_radius"], d["cell_size"], min(1 << 27, max(1 << 22, bound)))
     elif sink == "probe":
         probes = tracer.collect_probe_positions()
         # store sizing, reference src/Renderer.cpp:382-390

@@ -147,7 +147,13 @@ RenderResult renderFrame(const LoadedScene& scene, ProgressCallback progress, Pr
     }
     else
     {
-        check(rt_set_splat(tracer.ptr, derived.minSplatRadius, derived.cellSize, 1u << 22));
+        // the reference's DensityGrid grows without bound; here it is sized for the most cells the
+        // pass can touch (one per deposit), between 4 Mi and 128 Mi cells
+        const uint64_t depositBound = static_cast<uint64_t>(settings.photonsPerLight) *
+                                      static_cast<uint64_t>(std::max<int64_t>(1, flat.scene.light_count)) *
+                                      (static_cast<uint64_t>(std::max(0, flat.scene.settings.bounce_threshold)) + 1);
+        const uint64_t densityCells = std::min<uint64_t>(1ull << 27, std::max<uint64_t>(1ull << 22, depositBound));
+        check(rt_set_splat(tracer.ptr, derived.minSplatRadius, derived.cellSize, densityCells));
         check(rt_reset(tracer.ptr));
     }
 
