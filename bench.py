@@ -62,6 +62,10 @@ def main():
                     help="weak: every GPU traces the scene's full photon budget (global budget = N x scene); "
                          "strong: the scene's budget is split across the GPUs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend (nccl = RCCL; gloo only to rehearse the multi-rank path on one GPU)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="rehearsal: every rank uses GPU 0 (with --backend gloo)")
     ap.add_argument("--cpu-photons", type=int, default=40_000_000,
                     help="photons per light of the CPU baseline sample (about 20 s of CPU work)")
     args = ap.parse_args()
@@ -75,10 +79,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the photon pass has no CPU fallback")
+    if args.share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group("gloo")
 
     rt = importlib.import_module("ray-tracer_amd")
     parallel = importlib.import_module("ray-tracer_amd.parallel")

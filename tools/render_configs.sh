@@ -1,6 +1,6 @@
 # Full-size frames of the configuration scenes through the CLI (run on the GPU box from the repository root).
 mkdir -p gpurun_out/renders
-for S in CornellBox CornellBoxGlassMirrorDiffuse MirrorKnot4k MultiCameraTest; do
+for S in ${@:-CornellBox CornellBoxGlassMirrorDiffuse MirrorKnot4k MultiCameraTest CBGMD_stochastic128 MirrorBombardment-200M}; do
   python3 - "$S" <<'PY'
 import json, sys
 name = sys.argv[1]
