@@ -1616,6 +1616,9 @@ int32_t rt_trace(rt_tracer* tracer, const rt_trace_params* params)
                 // parked photons are in no particular order: short runs, for balance
                 chunk = std::min<uint64_t>(level > 0 ? 256 : 4096, std::max<uint64_t>(64, chunk)) & ~63ull;
                 launch.chunk = static_cast<uint32_t>(chunk);
+                // the last sixteenth of a launch goes out in pieces a quarter as long
+                launch.tailChunk = static_cast<uint32_t>(std::max<uint64_t>(64, (chunk / 4) & ~63ull));
+                launch.fullClaims = (work - work / 16) / chunk;
             }
             const uint64_t wavesNeeded = (work + 63) / 64;
             const int blocks = static_cast<int>(std::min<uint64_t>(static_cast<uint64_t>(residentBlocks), (wavesNeeded + 3) / 4));

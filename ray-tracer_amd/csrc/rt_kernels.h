@@ -109,7 +109,9 @@ struct TraceArgs
     RecordView records;
     DeviceCounters* counters;
     unsigned long long* workCounter;
-    uint32_t chunk;                 // photon ids a wave claims at a time (<= 4096, multiple of 64)
+    uint32_t chunk;                 // photon ids a wave claims at a time (<= 4096, multiple of 64) ...
+    uint32_t tailChunk;             // ... for the first `fullClaims` claims of the launch, then this many: the
+    uint64_t fullClaims;            // end of a launch is handed out in small pieces so that the waves end together
     const uint32_t* emissionOrder;  // optional: position in the pass -> photon id, sorted by emission cell
     uint64_t firstPhoton;
     uint64_t photonCount;  // per light

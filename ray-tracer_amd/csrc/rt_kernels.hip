@@ -524,12 +524,15 @@ __global__ __launch_bounds__(kTraceThreads) void traceKernel(const TraceArgs a)
                 unsigned long long fresh = 0;
                 if (lane == 0)
                 {
-                    fresh = atomicAdd(a.workCounter, static_cast<unsigned long long>(a.chunk));
+                    fresh = atomicAdd(a.workCounter, 1ull);  // the number of this claim
                 }
-                chunkBase = __shfl(fresh, 0, 64);
+                const unsigned long long claim = __shfl(fresh, 0, 64);
+                const bool full = claim < a.fullClaims;
+                const unsigned long long size = full ? a.chunk : a.tailChunk;
+                chunkBase = full ? claim * a.chunk : a.fullClaims * a.chunk + (claim - a.fullClaims) * a.tailChunk;
                 chunkNext = 0;
                 chunkCount = chunkBase < totalWork
-                                 ? static_cast<uint32_t>(totalWork - chunkBase < a.chunk ? totalWork - chunkBase : a.chunk)
+                                 ? static_cast<uint32_t>(totalWork - chunkBase < size ? totalWork - chunkBase : size)
                                  : 0u;
                 exhausted = chunkCount == 0;
             }
