@@ -502,6 +502,54 @@ def test_furnace_ledger_at_scale(rt, scene_opener):
     assert abs(c2["deposited_power"][0] - c["deposited_power"][0]) / expected < 1e-9
 
 
+@pytest.mark.parametrize("photons", [1, 63, 65, 4097])
+def test_ragged_passes_equal_oracle(rt, scene_opener, photons):
+    """Passes that do not fill a wave, a run or the grid (three lights, so the id space is ragged
+    as well): paths and counters as the oracle's."""
+    entry = dict(SCENES["mixed"], photons_per_light=photons)
+    scene, tracer, orc = _open(rt, scene_opener, entry)
+    total = photons * scene.desc.light_count
+    tracer.reset()
+    tracer.trace(sink_mode=0, record_photons=total)
+    got, c = tracer.records(), tracer.counters()
+    ref = orc.trace(rng_mode=O.RNG_COUNTER, math_mode=O.MATH_PORTABLE, threads=2, record_photons=total)
+    assert c["photons"] == total == ref["photons"]
+    for k in ("casts", "bounces", "deposits"):
+        assert c[k] == ref[k], k
+    assert_bits_equal(got["emitted"], ref["emitted"], "emitted")
+    assert_bits_equal(got["bounce_f64"], ref["bounce_f64"], "hits")
+    assert np.array_equal(got["bounce_i32"], ref["bounce_i32"]), "ids"
+
+
+def test_empty_inputs(rt, scene_opener):
+    """Nothing to trace, nothing to hit, nothing to keep: no crash, no hang, the obvious counters."""
+    entry = dict(SCENES["mixed"], photons_per_light=2000)
+    scene, tracer, orc = _open(rt, scene_opener, entry)
+    lights = scene.desc.light_count
+    # an empty photon range
+    tracer.reset()
+    tracer.trace(sink_mode=0, first_photon=2000, photon_count=0)
+    c = tracer.counters()
+    assert c["photons"] == 0 and c["casts"] == 0
+    # no probes: every deposit is culled, the store stays empty
+    tracer.set_probes(np.zeros((0, 3)), 10.0, 10.0, 64)
+    tracer.reset()
+    tracer.trace(sink_mode=1)
+    c = tracer.counters()
+    assert c["photons"] == 2000 * lights and c["kept"] == 0 and c["store_size"] == 0 and c["culled"] == c["deposits"] > 0
+    assert tracer.store().shape[0] == 0
+    # a scene without volumes: every photon escapes on its first cast
+    scene.desc.volume_count = 0
+    bare = rt.Tracer(scene)
+    bare.reset()
+    bare.trace(sink_mode=0)
+    c = bare.counters()
+    assert c["photons"] == c["casts"] == 2000 * lights and c["bounces"] == 0
+    rays = np.array([[0.0, 0.0, 0.0, 0.0, 0.0, 1.0]])
+    _, ids = bare.cast_rays(rays)
+    assert ids[0, 0] == 0
+
+
 def test_errors_are_codes_not_crashes(rt, scene_opener, tracer_mod):
     scene, tracer, _ = _open(rt, scene_opener, SCENES["furnace"])
     with pytest.raises(tracer_mod.TracerError) as e:
