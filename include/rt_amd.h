@@ -66,6 +66,8 @@ typedef struct rt_counters
     uint64_t splat_luminance_clamped; /* WorkerDebug::splatLuminanceClamped()         */
     uint64_t density_cells;           /* DensityGrid::cellCount()                     */
     uint64_t density_deposits;        /* DensityGrid::depositCount()                  */
+    uint64_t density_dropped;         /* deposits the grid could not take (table full, or a cell beyond +-2^20
+                                         cells from the origin); the reference's grid has no limit, so this is 0 there */
     double deposited_power[3];        /* sum of photon power over all non-delta bounces */
 } rt_counters;
 

@@ -1692,14 +1692,10 @@ int32_t rt_read_counters(rt_tracer* tracer, rt_counters* out)
         out->splat_luminance_clamped = dc.splatLuminanceClamped;
         out->density_cells = dc.densityCells;
         out->density_deposits = dc.densityDeposits - dc.densityOverflow;
+        out->density_dropped = dc.densityOverflow;
         for (int k = 0; k < 3; ++k)
         {
             out->deposited_power[k] = dc.power[k];
-        }
-        if (dc.densityOverflow != 0)
-        {
-            throw ApiError(RT_ERR_STATE, "density grid overflow: " + std::to_string(dc.densityOverflow) +
-                                             " deposits lost; raise density_capacity in rt_set_splat");
         }
     });
 }

@@ -41,6 +41,49 @@ def prepare_sinks(rt, scene, tracer, sink):
     return info
 
 
+def render_frame(rt, scene, tracer, buffers, rank=0, world=1, dist=None):
+    """One frame on this rank's GPU, reduced over the ranks: Renderer::renderFrame (reference
+    src/Renderer.cpp:222-700) with the photon indices sharded.
+
+    `buffers[c]` is the torch tensor bound as camera c's buffer (bind_camera_buffer), so that the
+    collective reduces it in place.  Probe-gather mode: every rank runs the probe pass and builds
+    the same keep-test index, rank 0 alone deposits the emitter faces (they must enter the sum
+    once), every rank traces its share into its own store and gathers it into its own camera
+    buffers — the gather is linear in the deposits (reference src/ProbeGather.cpp:653-727) — and
+    one all-reduce(sum) per camera makes the frame.  Splat mode: the trace accumulates into the
+    buffers directly, then the same all-reduce.  Returns the reduced counters."""
+    from . import parallel
+
+    d = derive(rt, scene)
+    photons = int(scene.settings.photons_per_light)
+    first, count = parallel.shard_range(photons, rank, world)
+    cameras = range(scene.desc.camera_count)
+    gathering = [c for c in cameras
+                 if scene.desc.cameras[c].bounce_filter < 0 and scene.desc.cameras[c].light_filter < 0]
+    if scene.settings.use_probe_gather:
+        cell = d["scene_depth_footprint"] if d["scene_depth_footprint"] > 0.0 else d["cell_size"]
+        tracer.set_probes_from_cameras(d["keep_radius"], d["keep_radius"], 256, int(scene.settings.bounce_store_capacity))
+        tracer.reset()
+        if rank == 0:
+            tracer.deposit_emitters(max(cell * 0.5, 1e-6))
+        tracer.trace(sink_mode=rt.tracer.SINK_PROBE, first_photon=first, photon_count=count)
+        for c in gathering:
+            tracer.gather(c, cell, d["min_splat_radius"])
+    else:
+        prepare_sinks(rt, scene, tracer, "splat")
+        tracer.reset()
+        tracer.trace(sink_mode=rt.tracer.SINK_SPLAT, first_photon=first, photon_count=count)
+    counters = tracer.counters()  # waits for the stream
+    parallel.all_reduce_sum(list(buffers), dist)
+    names = ("photons", "casts", "bounces", "deposits", "kept", "culled", "store_attempted", "store_size", "splat_total")
+    if world > 1:
+        import torch
+        totals = torch.tensor([int(counters[k]) for k in names], dtype=torch.int64, device=buffers[0].device)
+        parallel.all_reduce_sum([totals], dist)
+        counters = dict(counters, **dict(zip(names, (int(v) for v in totals.tolist()))))
+    return counters
+
+
 def cpu_baseline(rt, scene_path, sink, setup, photons):
     """Time the CPU path on a bounded sample of the same workload (same scene, `photons`
     photons per light instead of the full budget; cost is linear in photons).

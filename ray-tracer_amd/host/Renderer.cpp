@@ -186,6 +186,11 @@ RenderResult renderFrame(const LoadedScene& scene, ProgressCallback progress, Pr
     stage("photon pass (sort + trace)");
     result.photonPassSeconds =
         std::chrono::duration<double>(std::chrono::steady_clock::now() - photonPassStart).count();
+    if (counters.density_dropped > 0)
+    {
+        std::cout << "Density grid: " << counters.density_dropped
+                  << " deposits not recorded (grid full or cell out of range); the image is not affected" << std::endl;
+    }
     result.photons = counters.photons;
     result.casts = counters.casts;
     result.bounces = counters.bounces;

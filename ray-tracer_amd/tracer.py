@@ -15,7 +15,7 @@ RT_OK = 0
 COUNTER_FIELDS = (
     "photons", "casts", "bounces", "deposits", "kept", "culled", "store_attempted", "store_size",
     "store_dropped", "splat_total", "splat_radius_clamped", "splat_luminance_clamped", "density_cells",
-    "density_deposits",
+    "density_deposits", "density_dropped",
 )
 
 

@@ -1,0 +1,46 @@
+"""A whole frame sharded over two ranks (gloo, both on the test box's one GPU) equals the frame of
+one rank: same counters, camera buffers equal up to the order of float sums.  Probe-gather mode
+(per-rank store and gather, emitter deposits on rank 0 only) and splat mode."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import REPO
+
+pytestmark = pytest.mark.gpu
+WORKER = os.path.join(REPO, "tests", "frame_ranks_worker.py")
+
+
+def render(ranks, scene, photons, probe_gather, out):
+    args = [WORKER, os.path.join(REPO, scene), str(photons), "1" if probe_gather else "0", out]
+    if ranks == 1:
+        cmd = [sys.executable] + args
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks),
+               "--master-addr", "127.0.0.1", "--master-port", "29547"] + args
+    r = subprocess.run(cmd, cwd=REPO, capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    return np.load(out + ".npz"), json.load(open(out + ".json"))
+
+
+@pytest.mark.parametrize("probe_gather", [True, False])
+@pytest.mark.parametrize("scene,photons", [("tests/scenes/mixed.json", 30_001), ("scenes/MultiCameraTest.json", 200_000)])
+def test_two_rank_frame_equals_one_rank_frame(tmp_path, scene, photons, probe_gather):
+    one, c1 = render(1, scene, photons, probe_gather, str(tmp_path / "one"))
+    two, c2 = render(2, scene, photons, probe_gather, str(tmp_path / "two"))
+    for k in ("photons", "casts", "bounces", "deposits", "kept", "culled", "splat_total"):
+        assert c1[k] == c2[k], k
+    assert c1["bounces"] > 0
+    lit = 0
+    for name in one.files:
+        a, b = one[name], two[name]
+        peak = float(np.abs(a).max())
+        lit += peak > 0
+        # sums of the same terms in another order
+        np.testing.assert_allclose(b, a, rtol=3e-4, atol=2e-6 * max(peak, 1e-30))
+    assert lit > 0
