@@ -820,7 +820,7 @@ bool buildProbesOnDevice(rt_tracer* tracer, const double* probes, bool probesOnD
     check(hipStreamSynchronize(stream), "hipStreamSynchronize");
 
     uint64_t slots = 16;
-    while (slots < 2 * cellCount + 1)
+    while (slots < 4 * cellCount + 1)
     {
         slots <<= 1;
     }
@@ -829,7 +829,7 @@ bool buildProbesOnDevice(rt_tracer* tracer, const double* probes, bool probesOnD
     tracer->slotCount.allocate(slots);
     tracer->probePoints.allocate(3 * n);
     tracer->slotCount.zero(stream);
-    tracer->packedCells.allocate(slots);
+    tracer->packedCells.allocate(slots + 1);  // the keep test reads 8 bytes past an entry
     check(hipMemsetAsync(tracer->packedCells.ptr, 0xFF, slots * sizeof(rtd::PackedCell), stream), "hipMemsetAsync");
     rtd::launchProbeTable(keysOut.ptr, orderOut.ptr, points.ptr, n, tracer->slotKey.ptr, tracer->slotStart.ptr,
                           tracer->slotCount.ptr, tracer->packedCells.ptr, slots - 1, tracer->probePoints.ptr, stream);
@@ -852,7 +852,7 @@ bool buildProbesOnDevice(rt_tracer* tracer, const double* probes, bool probesOnD
     check(hipMemcpyAsync(&nearCount, scalars.ptr, sizeof(nearCount), hipMemcpyDeviceToHost, stream), "hipMemcpyAsync runs");
     check(hipStreamSynchronize(stream), "hipStreamSynchronize");
     uint64_t nearSlots = 16;
-    while (nearSlots < 2 * nearCount + 1)
+    while (nearSlots < 4 * nearCount + 1)
     {
         nearSlots <<= 1;
     }
@@ -860,7 +860,7 @@ bool buildProbesOnDevice(rt_tracer* tracer, const double* probes, bool probesOnD
     tracer->nearBits.allocate(nearSlots);
     check(hipMemsetAsync(tracer->nearKey.ptr, 0xFF, nearSlots * sizeof(unsigned long long), stream), "hipMemsetAsync");
     tracer->nearBits.zero(stream);
-    tracer->nearEntries.allocate(nearSlots);
+    tracer->nearEntries.allocate(nearSlots + 1);
     check(hipMemsetAsync(tracer->nearEntries.ptr, 0xFF, nearSlots * sizeof(rtd::NearEntry), stream), "hipMemsetAsync");
     rtd::launchNeighbourTable(nearOut.ptr, bitsOut.ptr, candidates, tracer->nearKey.ptr, tracer->nearBits.ptr,
                               tracer->nearEntries.ptr, nearSlots - 1, stream);

@@ -23,7 +23,7 @@
 // Optional divergence census (build with -DRT_DIAG): wave-level trip counts and active
 // lanes of the traversal loops, printed when a tracer is destroyed.
 #ifdef RT_DIAG
-__device__ unsigned long long g_rtDiag[16];
+__device__ unsigned long long g_rtDiag[32];
 #endif
 #if defined(RT_DIAG) && RT_DIAG == 1
 #define RT_DIAG_TRIP(slot)                                                                     \

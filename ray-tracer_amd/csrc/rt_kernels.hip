@@ -92,36 +92,130 @@ RT_DEV bool probeCellHas(const ProbeView& pv, int64_t kx, int64_t ky, int64_t kz
     }
 }
 
-// probeCellHas through the packed table: one 16-byte entry per probe of the slot sequence.
-RT_DEV bool packedCellHas(const ProbeView& pv, int64_t kx, int64_t ky, int64_t kz, const Vec& p, double r2)
+RT_DEV unsigned long long packProbeCell(int64_t kx, int64_t ky, int64_t kz)
 {
-    const unsigned long long key = (static_cast<unsigned long long>(kx + kPackLimit) << 42) |
-                                   (static_cast<unsigned long long>(ky + kPackLimit) << 21) |
-                                   static_cast<unsigned long long>(kz + kPackLimit);
-    uint64_t slot = cellHash(kx, ky, kz) & pv.slotMask;
-    while (true)
+    return (static_cast<unsigned long long>(kx + kPackLimit) << 42) | (static_cast<unsigned long long>(ky + kPackLimit) << 21) |
+           static_cast<unsigned long long>(kz + kPackLimit);
+}
+
+// The keep test through the neighbourhood filter, as one loop with ONE load per trip.  Every lane
+// walks its own chain of dependent reads (filter entry -> cell entry -> probe points -> next cell
+// ...), and a wave pays a memory round trip per trip of whichever loop it is in; nested per-table
+// loops cost the sum of the longest chain of each loop over the wave, this loop costs the longest
+// total of one lane.  All three tables are read with the same 24-byte load (a 16-byte entry plus
+// the 8 bytes after it, or one probe position), so the tables carry one entry of padding.
+// Order: the deposit's own cell first (on a surface the camera sees it usually holds a probe in
+// reach), then the other occupied cells (their order made no measurable difference), skipping
+// those whose box lies farther from p than the
+// keep radius (gaps in cell units; the bound carries 1e-6 of slack against the rounding of the
+// cell index).
+RT_DEV bool anyProbeInNeighbourhood(const ProbeView& pv, const Vec& p, double r2, int64_t cx, int64_t cy, int64_t cz)
+{
+    typedef uint32_t Uint4At8 __attribute__((ext_vector_type(4), aligned(8)));
+    constexpr uint32_t kCentreBit = 1u << 13;
+    enum { kFilter = 0, kCell = 1, kPoints = 2, kFinished = 3 };
+    const double fx = p.x * pv.invCellSize - static_cast<double>(cx);
+    const double fy = p.y * pv.invCellSize - static_cast<double>(cy);
+    const double fz = p.z * pv.invCellSize - static_cast<double>(cz);
+    const double reach2 = r2 * pv.invCellSize * pv.invCellSize * (1.0 + 1e-6);
+
+    int phase = kFilter;
+    bool found = false;
+    uint32_t bits = 0;       // occupied neighbour cells not visited yet
+    uint32_t remaining = 0;  // probes of the current cell not tested yet
+    unsigned long long key = packProbeCell(cx, cy, cz);
+    uint64_t slot = cellHash(cx, cy, cz) & pv.nearMask;
+    const char* address = reinterpret_cast<const char*>(pv.nearEntries + slot);
+    while (phase != kFinished)
     {
-        const uint4 raw = *reinterpret_cast<const uint4*>(pv.packedCells + slot);
-        const unsigned long long seen = (static_cast<unsigned long long>(raw.y) << 32) | raw.x;
-        if (seen == key)
+        RT_DIAG_TRIP(12);
+        const Uint4At8 head = *reinterpret_cast<const Uint4At8*>(address);
+        const unsigned long long tail = *reinterpret_cast<const unsigned long long*>(address + 16);
+        const unsigned long long first = (static_cast<unsigned long long>(head.y) << 32) | head.x;
+        bool nextCell = false;
+        if (phase == kPoints)
         {
-            const double* pt = pv.points + 3ull * raw.z;
-            for (uint32_t i = 0; i < raw.w; ++i)
+            const double ddx = __builtin_bit_cast(double, first) - p.x;
+            const double ddy = __builtin_bit_cast(double, (static_cast<unsigned long long>(head.w) << 32) | head.z) - p.y;
+            const double ddz = __builtin_bit_cast(double, tail) - p.z;
+            if (ddx * ddx + ddy * ddy + ddz * ddz <= r2)
             {
-                const double ddx = pt[3 * i] - p.x, ddy = pt[3 * i + 1] - p.y, ddz = pt[3 * i + 2] - p.z;
-                if (ddx * ddx + ddy * ddy + ddz * ddz <= r2)
-                {
-                    return true;
-                }
+                found = true;
+                phase = kFinished;
             }
-            return false;
+            else if (--remaining == 0)
+            {
+                nextCell = true;
+            }
+            else
+            {
+                address += 3 * sizeof(double);
+            }
         }
-        if (seen == kEmptyKey)
+        else if (first == key)
         {
-            return false;
+            if (phase == kFilter)
+            {
+                bits = head.z;
+                nextCell = true;
+            }
+            else if (head.w == 0)
+            {
+                nextCell = true;
+            }
+            else
+            {
+                remaining = head.w;
+                phase = kPoints;
+                address = reinterpret_cast<const char*>(pv.points + 3ull * head.z);
+            }
         }
-        slot = (slot + 1) & pv.slotMask;
+        else if (first == kEmptyKey)
+        {
+            if (phase == kFilter)
+            {
+                phase = kFinished;  // no occupied cell around p
+            }
+            else
+            {
+                nextCell = true;
+            }
+        }
+        else if (phase == kFilter)
+        {
+            slot = (slot + 1) & pv.nearMask;
+            address = reinterpret_cast<const char*>(pv.nearEntries + slot);
+        }
+        else
+        {
+            slot = (slot + 1) & pv.slotMask;
+            address = reinterpret_cast<const char*>(pv.packedCells + slot);
+        }
+        if (nextCell)
+        {
+            phase = kFinished;
+            while (bits != 0)
+            {
+                const int b = (bits & kCentreBit) != 0 ? 13 : __builtin_ctz(bits);
+                bits &= ~(1u << b);
+                const int iz = b / 9, iy = (b / 3) % 3, ix = b % 3;
+                const double gx = ix == 0 ? fx : (ix == 1 ? 0.0 : 1.0 - fx);
+                const double gy = iy == 0 ? fy : (iy == 1 ? 0.0 : 1.0 - fy);
+                const double gz = iz == 0 ? fz : (iz == 1 ? 0.0 : 1.0 - fz);
+                if (gx * gx + gy * gy + gz * gz > reach2)
+                {
+                    continue;
+                }
+                const int64_t kx = cx + ix - 1, ky = cy + iy - 1, kz = cz + iz - 1;
+                key = packProbeCell(kx, ky, kz);
+                slot = cellHash(kx, ky, kz) & pv.slotMask;
+                address = reinterpret_cast<const char*>(pv.packedCells + slot);
+                phase = kCell;
+                break;
+            }
+        }
     }
+    return found;
 }
 
 // ProbeIndex::anyWithin, reference src/ProbeIndex.cpp:27-68.  The result is a pure
@@ -148,37 +242,7 @@ RT_DEV bool anyProbeWithin(const ProbeView& pv, const Vec& p)
         {
             return false;
         }
-        const unsigned long long key = (static_cast<unsigned long long>(cx + kPackLimit) << 42) |
-                                       (static_cast<unsigned long long>(cy + kPackLimit) << 21) |
-                                       static_cast<unsigned long long>(cz + kPackLimit);
-        uint64_t slot = cellHash(cx, cy, cz) & pv.nearMask;
-        uint32_t bits = 0;
-        while (true)
-        {
-            const uint4 raw = *reinterpret_cast<const uint4*>(pv.nearEntries + slot);
-            const unsigned long long seen = (static_cast<unsigned long long>(raw.y) << 32) | raw.x;
-            if (seen == key)
-            {
-                bits = raw.z;
-                break;
-            }
-            if (seen == kEmptyKey)
-            {
-                break;
-            }
-            slot = (slot + 1) & pv.nearMask;
-        }
-        while (bits != 0)
-        {
-            const int b = __builtin_ctz(bits);
-            bits &= bits - 1;
-            const int dz = b / 9 - 1, dy = (b / 3) % 3 - 1, dx = b % 3 - 1;
-            if (packedCellHas(pv, cx + dx, cy + dy, cz + dz, p, r2))
-            {
-                return true;
-            }
-        }
-        return false;
+        return anyProbeInNeighbourhood(pv, p, r2, cx, cy, cz);
     }
     const int64_t reach = pv.reach;
     for (int64_t dz = -reach; dz <= reach; ++dz)
@@ -1322,14 +1386,8 @@ __global__ void probePositionsKernel(const GatherPoint* points, uint64_t n, doub
 // ProbeIndex's constructor (reference src/ProbeIndex.cpp:5-25) hashes every probe into an
 // unordered_map of cells.  Here the probes are keyed by packed cell, sorted, and the runs of
 // equal keys become the cells of an open-addressed table; the 27-neighbour occupancy filter
-// is built the same way from the 27 keys around every occupied cell.  x is packed in the high
-// bits as in the trace kernel's filter lookup.
-RT_DEV unsigned long long packProbeCell(int64_t x, int64_t y, int64_t z)
-{
-    return (static_cast<unsigned long long>(x + kPackLimit) << 42) | (static_cast<unsigned long long>(y + kPackLimit) << 21) |
-           static_cast<unsigned long long>(z + kPackLimit);
-}
-
+// is built the same way from the 27 keys around every occupied cell (keys: packProbeCell, x in the
+// high bits).
 __global__ void probeKeysKernel(const ProbeBuild b, uint32_t* unpackable)
 {
     const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -1482,7 +1540,7 @@ size_t stackBytes(const SceneView& scene, int threads)
 #ifdef RT_DIAG
 void printDiagnostics()
 {
-    unsigned long long host[16] = {};
+    unsigned long long host[32] = {};
     if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_rtDiag), sizeof(host)) != hipSuccess) return;
 #if RT_DIAG == 2
     const char* names[] = {"kernel", "casts", "node loops", "triangle loops", "refill", "deposit", "scatter"};
@@ -1492,14 +1550,15 @@ void printDiagnostics()
                 host[0] ? 100.0 * static_cast<double>(host[k]) / static_cast<double>(host[0]) : 0.0);
     }
 #else
-    const char* names[] = {"mesh casts", "outer rounds", "node steps", "triangle tests", "main loop", "keep tests"};
-    for (int k = 0; k < 6; ++k)
+    const char* names[] = {"mesh casts", "outer rounds", "node steps", "triangle tests", "main loop", "keep tests",
+                           "keep-test loads"};
+    for (int k = 0; k < 7; ++k)
     {
         fprintf(stderr, "[rt diag] %-15s wave trips %12llu  active lanes %14llu  (%.1f / 64)\n", names[k], host[2 * k],
                 host[2 * k + 1], host[2 * k] ? static_cast<double>(host[2 * k + 1]) / host[2 * k] : 0.0);
     }
 #endif
-    unsigned long long zero[16] = {};
+    unsigned long long zero[32] = {};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_rtDiag), zero, sizeof(zero));
 }
 #endif
