@@ -256,6 +256,13 @@ class Tracer:
         names = ("camera_rays", "delta_extensions", "misses")
         return out, dict(zip(names, (int(v) for v in stats)))
 
+    def count_gather_points(self, camera=0):
+        """Run one camera's probe pass and leave the records on the device; returns their number."""
+        n = C.c_uint64()
+        stats = np.zeros(3, dtype=np.uint64)
+        _check(tracer_lib().rt_collect_gather_points(self._handle, camera, None, 0, C.byref(n), _ptr(stats)))
+        return int(n.value)
+
     def collect_probe_positions(self):
         """Gather-point positions of every camera, in camera order (what the reference's
         Renderer feeds into ProbeIndex, src/Renderer.cpp:101-131)."""

@@ -58,3 +58,27 @@ def test_no_gpu_means_loud_failure_not_fallback(rt):
     import numpy as np
     with pytest.raises(tracer.TracerError):
         tracer.rows("rt_intersect_spheres", np.zeros((1, 10)), 8)
+
+
+def test_trace_kernels_keep_two_waves_per_simd():
+    """The trace kernels sit at the 256-register edge: one register more and the compiler falls
+    back to one wave per SIMD, which halves the throughput without failing anything else.  The
+    build keeps the compiler's resource remarks; every trace variant must report two waves per
+    SIMD, no scratch and no spilled vector registers."""
+    import re
+    path = os.path.join(REPO, "ray-tracer_amd", "csrc", "build", "rt_kernels.resources")
+    if not os.path.exists(path):
+        pytest.skip("no resource remarks: build ray-tracer_amd/csrc with make first")
+    text = open(path).read()
+    blocks = re.split(r"remark: Function Name: ", text)[1:]
+    seen = 0
+    for block in blocks:
+        name = block.split()[0]
+        if "traceKernel" not in name:
+            continue
+        seen += 1
+        fields = dict(re.findall(r"remark:\s+([A-Za-z /\[\]]+?): (\w+) \[", block))
+        assert fields["Occupancy [waves/SIMD]"] == "2", (name, fields)
+        assert fields["ScratchSize [bytes/lane]"] == "0", (name, fields)
+        assert fields["VGPRs Spill"] == "0", (name, fields)
+    assert seen == 12
