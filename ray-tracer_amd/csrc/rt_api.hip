@@ -1896,7 +1896,7 @@ int32_t rt_gather(rt_tracer* tracer, int32_t camera, double gather_cell_size, do
         const double cellSize = gather_cell_size > 0.0 ? gather_cell_size : 1.0;  // reference src/BounceStore.cpp:44
 
         // index: key every record by its cell, sort (key, record) pairs
-        DeviceArray<unsigned long long> keysIn, keysOut, stats;
+        DeviceArray<unsigned long long> keysIn, keysOut, stats, counts;
         DeviceArray<uint32_t> orderIn, orderOut;
         DeviceArray<unsigned char> scratch;
         uint64_t indexed = 0;
@@ -1914,13 +1914,13 @@ int32_t rt_gather(rt_tracer* tracer, int32_t camera, double gather_cell_size, do
             rtd::sortStoreKeys(scratch.ptr, bytes, keysIn.ptr, keysOut.ptr, orderIn.ptr, orderOut.ptr, n, tracer->stream);
             check(hipGetLastError(), "store sort");
             // records whose cell could not be packed sort to the end; find where they start
-            std::vector<unsigned long long> hostKeys(n);
-            check(hipMemcpyAsync(hostKeys.data(), keysOut.ptr, n * sizeof(unsigned long long), hipMemcpyDeviceToHost,
-                                 tracer->stream),
-                  "hipMemcpyAsync keys");
+            counts.allocate(1);
+            rtd::launchCountIndexed(keysOut.ptr, n, counts.ptr, tracer->stream);
+            unsigned long long hostIndexed = 0;
+            check(hipMemcpyAsync(&hostIndexed, counts.ptr, sizeof(hostIndexed), hipMemcpyDeviceToHost, tracer->stream),
+                  "hipMemcpyAsync indexed");
             check(hipStreamSynchronize(tracer->stream), "hipStreamSynchronize");
-            indexed = static_cast<uint64_t>(
-                std::lower_bound(hostKeys.begin(), hostKeys.end(), rtd::kEmptyKey) - hostKeys.begin());
+            indexed = hostIndexed;
         }
         stats.allocate(2);
         stats.zero(tracer->stream);

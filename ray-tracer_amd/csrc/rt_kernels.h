@@ -175,6 +175,8 @@ void launchStoreKeys(const float* store, uint64_t n, double invCellSize, unsigne
 size_t sortStoreKeys(void* scratch, size_t scratchBytes, const unsigned long long* keysIn,
                      unsigned long long* keysOut, const uint32_t* orderIn, uint32_t* orderOut, uint64_t n,
                      hipStream_t stream);
+// out[0] = number of leading keys below the "no cell" key (records of unpackable cells sort to the end)
+void launchCountIndexed(const unsigned long long* sortedKeys, uint64_t n, unsigned long long* out, hipStream_t stream);
 void launchGather(const GatherArgs& args, hipStream_t stream);
 // Device-side build of the probe grid (rt_set_probes): see the kernels in rt_kernels.hip.
 struct ProbeBuild

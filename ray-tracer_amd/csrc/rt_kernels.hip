@@ -1143,6 +1143,11 @@ RT_DEV uint64_t lowerBound(const unsigned long long* keys, uint64_t n, unsigned 
     return lo;
 }
 
+__global__ void countIndexedKernel(const unsigned long long* keys, uint64_t n, unsigned long long* out)
+{
+    out[0] = lowerBound(keys, n, kEmptyKey);
+}
+
 RT_DEV int64_t clampCell(int64_t v) { return v < -kPackLimit ? -kPackLimit : (v > kPackLimit - 1 ? kPackLimit - 1 : v); }
 
 // testing::gatherRadiance, reference src/ProbeGather.cpp:596-728, for one gather point.
@@ -1714,6 +1719,11 @@ size_t scanCounts(void* scratch, size_t scratchBytes, const uint32_t* counts, ui
     hipcub::TransformInputIterator<uint64_t, WidenCount, const uint32_t*> wide(counts, WidenCount());
     (void)hipcub::DeviceScan::ExclusiveSum(scratch, bytes, wide, offsets, static_cast<int>(n), stream);
     return bytes;
+}
+
+void launchCountIndexed(const unsigned long long* sortedKeys, uint64_t n, unsigned long long* out, hipStream_t stream)
+{
+    hipLaunchKernelGGL(countIndexedKernel, dim3(1), dim3(1), 0, stream, sortedKeys, n, out);
 }
 
 void launchGather(const GatherArgs& args, hipStream_t stream)
