@@ -152,8 +152,6 @@ struct rt_tracer
     DeviceArray<int64_t> slotKey;
     DeviceArray<uint32_t> slotStart, slotCount;
     DeviceArray<double> probePoints;
-    DeviceArray<unsigned long long> nearKey;
-    DeviceArray<uint32_t> nearBits;
     DeviceArray<rtd::PackedCell> packedCells;
     DeviceArray<rtd::NearEntry> nearEntries;
     rtd::ProbeView probeView{};
@@ -856,14 +854,9 @@ bool buildProbesOnDevice(rt_tracer* tracer, const double* probes, bool probesOnD
     {
         nearSlots <<= 1;
     }
-    tracer->nearKey.allocate(nearSlots);
-    tracer->nearBits.allocate(nearSlots);
-    check(hipMemsetAsync(tracer->nearKey.ptr, 0xFF, nearSlots * sizeof(unsigned long long), stream), "hipMemsetAsync");
-    tracer->nearBits.zero(stream);
     tracer->nearEntries.allocate(nearSlots + 1);
     check(hipMemsetAsync(tracer->nearEntries.ptr, 0xFF, nearSlots * sizeof(rtd::NearEntry), stream), "hipMemsetAsync");
-    rtd::launchNeighbourTable(nearOut.ptr, bitsOut.ptr, candidates, tracer->nearKey.ptr, tracer->nearBits.ptr,
-                              tracer->nearEntries.ptr, nearSlots - 1, stream);
+    rtd::launchNeighbourTable(nearOut.ptr, bitsOut.ptr, candidates, tracer->nearEntries.ptr, nearSlots - 1, stream);
     check(hipGetLastError(), "probe grid build");
     check(hipStreamSynchronize(stream), "hipStreamSynchronize");
 
@@ -877,8 +870,6 @@ bool buildProbesOnDevice(rt_tracer* tracer, const double* probes, bool probesOnD
     pv.invCellSize = invCellSize;
     pv.keepRadius = keepRadius;
     pv.reach = reach;
-    pv.nearKey = tracer->nearKey.ptr;
-    pv.nearBits = tracer->nearBits.ptr;
     pv.nearMask = nearSlots - 1;
     pv.packedCells = tracer->packedCells.ptr;
     pv.nearEntries = tracer->nearEntries.ptr;
@@ -1261,13 +1252,9 @@ void setProbes(rt_tracer* tracer, const double* probes, bool probesOnDevice, uin
 
     // no neighbourhood filter on this path (the device build above makes it whenever it applies):
     // the keep test scans the cells within reach
-    pv.nearKey = nullptr;
-    pv.nearBits = nullptr;
     pv.nearMask = 0;
     pv.packedCells = nullptr;
     pv.nearEntries = nullptr;
-    tracer->nearKey.release();
-    tracer->nearBits.release();
     tracer->packedCells.release();
     tracer->nearEntries.release();
     tracer->probesSet = true;

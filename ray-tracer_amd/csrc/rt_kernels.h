@@ -26,14 +26,11 @@ struct ProbeView
     // Neighbourhood filter (only when reach == 1 and every probe cell packs into 3 x 21
     // bits; nearMask == 0 otherwise): every cell that has an occupied cell among its 27
     // neighbours, with one bit per occupied neighbour, bit (dz+1)*9 + (dy+1)*3 + (dx+1).
-    const unsigned long long* nearKey;  // [nearMask + 1] packed cell, kEmptyKey when free
-    const uint32_t* nearBits;           // [nearMask + 1]
     uint64_t nearMask;
-    // The same two tables as single 16-byte entries (one load per lookup), filled together with
-    // the filter: packedCells[slot] mirrors slotKey / slotStart / slotCount, nearEntries[slot]
-    // mirrors nearKey / nearBits.  A free slot holds kEmptyKey.
+    // Both tables as single 16-byte entries (one load per lookup): packedCells[slot] mirrors
+    // slotKey / slotStart / slotCount, nearEntries[slot] is the filter.  A free slot holds kEmptyKey.
     const PackedCell* packedCells;
-    const NearEntry* nearEntries;
+    const NearEntry* nearEntries;       // [nearMask + 1]
 };
 
 struct alignas(16) PackedCell
@@ -215,8 +212,7 @@ void launchProbeTable(const unsigned long long* sortedKeys, const uint32_t* sort
 void launchNeighbourKeys(const unsigned long long* sortedKeys, uint64_t n, unsigned long long* outKeys,
                          uint32_t* outBits, unsigned long long* cursor, hipStream_t stream);
 void launchNeighbourTable(const unsigned long long* sortedKeys, const uint32_t* sortedBits, uint64_t n,
-                          unsigned long long* nearKey, uint32_t* nearBits, NearEntry* nearEntries, uint64_t nearMask,
-                          hipStream_t stream);
+                          NearEntry* nearEntries, uint64_t nearMask, hipStream_t stream);
 void launchProbeTest(const ProbeView& probes, int64_t n, const double* points, uint8_t* out, hipStream_t stream);
 
 }  // namespace rtd

@@ -1510,8 +1510,7 @@ __global__ void neighbourKeysKernel(const unsigned long long* keys, uint64_t n, 
 
 // sorted neighbour keys: the first of every run ORs the run's bits and enters the table
 __global__ void neighbourTableKernel(const unsigned long long* keys, const uint32_t* bits, uint64_t n,
-                                     unsigned long long* nearKey, uint32_t* nearBits, NearEntry* nearEntries,
-                                     uint64_t nearMask)
+                                     NearEntry* nearEntries, uint64_t nearMask)
 {
     const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -1526,12 +1525,11 @@ __global__ void neighbourTableKernel(const unsigned long long* keys, const uint3
     const int64_t y = static_cast<int64_t>((key >> 21) & ((1ull << 21) - 1)) - kPackLimit;
     const int64_t z = static_cast<int64_t>(key & ((1ull << 21) - 1)) - kPackLimit;
     uint64_t slot = cellHash(x, y, z) & nearMask;
-    while (atomicCAS(nearKey + slot, kEmptyKey, key) != kEmptyKey)
+    while (atomicCAS(&nearEntries[slot].key, kEmptyKey, key) != kEmptyKey)
     {
         slot = (slot + 1) & nearMask;
     }
-    nearBits[slot] = all;
-    nearEntries[slot] = NearEntry{key, all, 0u};
+    nearEntries[slot].bits = all;
 }
 
 int gridFor(int64_t n) { return static_cast<int>((n + 255) / 256); }
@@ -1793,12 +1791,11 @@ void launchNeighbourKeys(const unsigned long long* sortedKeys, uint64_t n, unsig
 }
 
 void launchNeighbourTable(const unsigned long long* sortedKeys, const uint32_t* sortedBits, uint64_t n,
-                          unsigned long long* nearKey, uint32_t* nearBits, NearEntry* nearEntries, uint64_t nearMask,
-                          hipStream_t stream)
+                          NearEntry* nearEntries, uint64_t nearMask, hipStream_t stream)
 {
     if (n == 0) return;
     hipLaunchKernelGGL(neighbourTableKernel, dim3(gridFor(static_cast<int64_t>(n))), dim3(256), 0, stream, sortedKeys, sortedBits,
-                       n, nearKey, nearBits, nearEntries, nearMask);
+                       n, nearEntries, nearMask);
 }
 
 void launchProbeTest(const ProbeView& probes, int64_t n, const double* points, uint8_t* out, hipStream_t stream)
