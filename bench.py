@@ -9,10 +9,10 @@ the scene's budget x N by default (weak scaling: every GPU traces the scene's 20
 photons, the frame holds N x 200 M) or the scene's budget itself with --scaling strong;
 then the per-camera buffers and the counters are summed across ranks with one RCCL
 all-reduce.  Inputs (scene, tree, probe grid) are resident in HBM before the timed
-region.  The metric counts ray casts that produced a valid hit.
+region.  The metric counts ray casts that produced a valid hit (a photon-bounce).
 
-Rank 0 prints ONE JSON line; see DESIGN.md "Measurement" for how `roofline` and
-`cpu_baseline` are defined.  `roofline` is that of the dominant kernel, traceKernel: its
+Rank 0 prints ONE JSON line.  `roofline` is that of the dominant kernel, traceKernel: achieved =
+algorithmic bytes of the launch (algorithmic_bytes_per_cast x casts + sink bytes) / its duration; its
 duration comes from HIP events the library records on the tracer's stream around that
 kernel (rt_read_timings); `roofline.traffic` is the HBM byte count of the same launch
 measured with rocprofv3 PMC passes and committed in profiles/traffic.json (null when the

@@ -181,9 +181,11 @@ int32_t rt_read_store(rt_tracer* tracer, float* records, uint64_t max_records, u
 /* DensityGrid cells: keys [n][3] int64, power [n][3] float, counts [n] uint64. */
 int32_t rt_read_density(rt_tracer* tracer, int64_t* keys, float* power, uint64_t* counts,
                         uint64_t max_cells, uint64_t* count);
-/* Per-bounce records of the last trace (layout: oracle.h / DESIGN.md "records"):
- * emitted [M][6], casts_valid [M][2], f64 [M][B][10], i32 [M][B][8], power [M][B][3]
- * with B = bounce_threshold + 1.  Any pointer may be NULL. */
+/* Per-bounce records of the last trace, M recorded photons, B = bounce_threshold + 1 slots each:
+ * emitted [M][6] (origin, direction), casts_valid [M][2] (casts, valid hits),
+ * f64 [M][B][10] (hit position 3, normal 3, distance, incoming direction 3),
+ * i32 [M][B][8] (photon index, bounce, volume, triangle, material, 0, delta flag, light),
+ * power [M][B][3] (the photon's colour at the hit).  Any pointer may be NULL. */
 int32_t rt_read_records(rt_tracer* tracer, uint64_t* recorded, double* emitted, int32_t* casts_valid,
                         double* bounce_f64, int32_t* bounce_i32, float* bounce_power);
 
