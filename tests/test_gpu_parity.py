@@ -565,6 +565,30 @@ def test_ragged_passes_equal_oracle(rt, scene_opener, photons):
     assert np.array_equal(got["bounce_i32"], ref["bounce_i32"]), "ids"
 
 
+@pytest.mark.parametrize("name", ["bombardment", "mixed"])
+def test_high_photon_indices_equal_oracle(rt, scene_opener, name):
+    """The last rank of an eight-GPU weak-scaling frame traces photon indices around 1.4e9 of a
+    1.6e9-photon budget (beyond 2^30, and for three lights ids beyond 2^32): paths and counters
+    of such a range are the oracle's."""
+    entry = dict(SCENES[name], photons_per_light=1_600_000_000)
+    scene, tracer, orc = _open(rt, scene_opener, entry)
+    first, count = 1_400_000_017, 3000
+    total = count * scene.desc.light_count
+    tracer.reset()
+    tracer.trace(sink_mode=0, first_photon=first, photon_count=count, record_photons=total)
+    got, c = tracer.records(), tracer.counters()
+    ref = orc.trace(rng_mode=O.RNG_COUNTER, math_mode=O.MATH_PORTABLE, threads=2, first_photon=first, photon_count=count,
+                    record_photons=total)
+    assert c["photons"] == total == ref["photons"]
+    for k in ("casts", "bounces", "deposits"):
+        assert c[k] == ref[k], k
+    assert ref["bounces"] > 0
+    assert_bits_equal(got["emitted"], ref["emitted"], "emitted")
+    assert_bits_equal(got["bounce_f64"], ref["bounce_f64"], "hits")
+    assert np.array_equal(got["bounce_i32"], ref["bounce_i32"]), "ids"
+    assert np.array_equal(got["bounce_power"], ref["bounce_power"]), "power"
+
+
 def test_empty_inputs(rt, scene_opener):
     """Nothing to trace, nothing to hit, nothing to keep: no crash, no hang, the obvious counters."""
     entry = dict(SCENES["mixed"], photons_per_light=2000)
