@@ -825,9 +825,9 @@ bool buildProbesOnDevice(rt_tracer* tracer, const double* probes, bool probesOnD
     tracer->slotKey.allocate(3 * slots);
     tracer->slotStart.allocate(slots);
     tracer->slotCount.allocate(slots);
-    tracer->probePoints.allocate(3 * n);
+    tracer->probePoints.allocate(3 * n + 2);  // ... and at a probe position
     tracer->slotCount.zero(stream);
-    tracer->packedCells.allocate(slots + 1);  // the keep test reads 8 bytes past an entry
+    tracer->packedCells.allocate(slots);
     check(hipMemsetAsync(tracer->packedCells.ptr, 0xFF, slots * sizeof(rtd::PackedCell), stream), "hipMemsetAsync");
     rtd::launchProbeTable(keysOut.ptr, orderOut.ptr, points.ptr, n, tracer->slotKey.ptr, tracer->slotStart.ptr,
                           tracer->slotCount.ptr, tracer->packedCells.ptr, slots - 1, tracer->probePoints.ptr, stream);
@@ -854,7 +854,7 @@ bool buildProbesOnDevice(rt_tracer* tracer, const double* probes, bool probesOnD
     {
         nearSlots <<= 1;
     }
-    tracer->nearEntries.allocate(nearSlots + 1);
+    tracer->nearEntries.allocate(nearSlots + 2);  // the keep test reads 40 bytes at an entry
     check(hipMemsetAsync(tracer->nearEntries.ptr, 0xFF, nearSlots * sizeof(rtd::NearEntry), stream), "hipMemsetAsync");
     rtd::launchNeighbourTable(nearOut.ptr, bitsOut.ptr, candidates, tracer->nearEntries.ptr, nearSlots - 1, stream);
     check(hipGetLastError(), "probe grid build");

@@ -27,16 +27,18 @@ struct ProbeView
     // bits; nearMask == 0 otherwise): every cell that has an occupied cell among its 27
     // neighbours, with one bit per occupied neighbour, bit (dz+1)*9 + (dy+1)*3 + (dx+1).
     uint64_t nearMask;
-    // Both tables as single 16-byte entries (one load per lookup): packedCells[slot] mirrors
-    // slotKey / slotStart / slotCount, nearEntries[slot] is the filter.  A free slot holds kEmptyKey.
+    // Both tables as single entries (one load per lookup): packedCells[slot] mirrors slotKey /
+    // slotStart / slotCount and carries the cell's first probe, nearEntries[slot] is the filter.
+    // A free slot holds kEmptyKey.
     const PackedCell* packedCells;
     const NearEntry* nearEntries;       // [nearMask + 1]
 };
 
-struct alignas(16) PackedCell
+struct alignas(16) PackedCell  // 48 bytes
 {
     unsigned long long key;  // packed cell coordinates
     uint32_t start, count;   // its probes in `points`
+    double first[3];         // the first of them (most cells hold one probe: no second read)
 };
 
 struct alignas(16) NearEntry

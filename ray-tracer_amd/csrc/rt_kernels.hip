@@ -102,8 +102,9 @@ RT_DEV unsigned long long packProbeCell(int64_t kx, int64_t ky, int64_t kz)
 // walks its own chain of dependent reads (filter entry -> cell entry -> probe points -> next cell
 // ...), and a wave pays a memory round trip per trip of whichever loop it is in; nested per-table
 // loops cost the sum of the longest chain of each loop over the wave, this loop costs the longest
-// total of one lane.  All three tables are read with the same 24-byte load (a 16-byte entry plus
-// the 8 bytes after it, or one probe position), so the tables carry one entry of padding.
+// total of one lane.  All three tables are read with the same 40-byte load (a filter entry and
+// what follows it, a cell entry with the cell's first probe, or a probe position and what
+// follows it), so the filter and the probe positions carry padding at their ends.
 // Order: the deposit's own cell first (on a surface the camera sees it usually holds a probe in
 // reach), then the other occupied cells (their order made no measurable difference), skipping
 // those whose box lies farther from p than the
@@ -130,27 +131,20 @@ RT_DEV bool anyProbeInNeighbourhood(const ProbeView& pv, const Vec& p, double r2
     {
         RT_DIAG_TRIP(12);
         const Uint4At8 head = *reinterpret_cast<const Uint4At8*>(address);
-        const unsigned long long tail = *reinterpret_cast<const unsigned long long*>(address + 16);
+        const Uint4At8 mid = *reinterpret_cast<const Uint4At8*>(address + 16);
+        const unsigned long long tail = *reinterpret_cast<const unsigned long long*>(address + 32);
         const unsigned long long first = (static_cast<unsigned long long>(head.y) << 32) | head.x;
-        bool nextCell = false;
+        const unsigned long long second = (static_cast<unsigned long long>(head.w) << 32) | head.z;
+        const unsigned long long third = (static_cast<unsigned long long>(mid.y) << 32) | mid.x;
+        const unsigned long long fourth = (static_cast<unsigned long long>(mid.w) << 32) | mid.z;
+        bool nextCell = false, testProbe = false;
+        double qx = 0.0, qy = 0.0, qz = 0.0;
         if (phase == kPoints)
         {
-            const double ddx = __builtin_bit_cast(double, first) - p.x;
-            const double ddy = __builtin_bit_cast(double, (static_cast<unsigned long long>(head.w) << 32) | head.z) - p.y;
-            const double ddz = __builtin_bit_cast(double, tail) - p.z;
-            if (ddx * ddx + ddy * ddy + ddz * ddz <= r2)
-            {
-                found = true;
-                phase = kFinished;
-            }
-            else if (--remaining == 0)
-            {
-                nextCell = true;
-            }
-            else
-            {
-                address += 3 * sizeof(double);
-            }
+            qx = __builtin_bit_cast(double, first);
+            qy = __builtin_bit_cast(double, second);
+            qz = __builtin_bit_cast(double, third);
+            testProbe = true;
         }
         else if (first == key)
         {
@@ -165,6 +159,11 @@ RT_DEV bool anyProbeInNeighbourhood(const ProbeView& pv, const Vec& p, double r2
             }
             else
             {
+                // the cell's entry carries its first probe; the others follow it in `points`
+                qx = __builtin_bit_cast(double, third);
+                qy = __builtin_bit_cast(double, fourth);
+                qz = __builtin_bit_cast(double, tail);
+                testProbe = true;
                 remaining = head.w;
                 phase = kPoints;
                 address = reinterpret_cast<const char*>(pv.points + 3ull * head.z);
@@ -190,6 +189,23 @@ RT_DEV bool anyProbeInNeighbourhood(const ProbeView& pv, const Vec& p, double r2
         {
             slot = (slot + 1) & pv.slotMask;
             address = reinterpret_cast<const char*>(pv.packedCells + slot);
+        }
+        if (testProbe)
+        {
+            const double ddx = qx - p.x, ddy = qy - p.y, ddz = qz - p.z;
+            if (ddx * ddx + ddy * ddy + ddz * ddz <= r2)
+            {
+                found = true;
+                phase = kFinished;
+            }
+            else if (--remaining == 0)
+            {
+                nextCell = true;
+            }
+            else
+            {
+                address += 3 * sizeof(double);
+            }
         }
         if (nextCell)
         {
@@ -1472,7 +1488,14 @@ __global__ void probeTableKernel(const unsigned long long* keys, const uint32_t*
     slotKey[3 * slot + 1] = y;
     slotKey[3 * slot + 2] = z;
     slotStart[slot] = static_cast<uint32_t>(i);
-    packedCells[slot] = PackedCell{key, static_cast<uint32_t>(i), count};
+    PackedCell cell;
+    cell.key = key;
+    cell.start = static_cast<uint32_t>(i);
+    cell.count = count;
+    cell.first[0] = grouped[3 * i + 0];
+    cell.first[1] = grouped[3 * i + 1];
+    cell.first[2] = grouped[3 * i + 2];
+    packedCells[slot] = cell;
 }
 
 // for every occupied cell, the 27 cells around it, each with the bit that says "my neighbour
