@@ -36,6 +36,10 @@ void rth_scene_free(rth_scene* scene);
  * size, [2] minimum splat radius, [3] probe keep radius. */
 int rth_frame_derive(const rt_scene* scene, double out[4]);
 
+/* The CLI's image writer (reference src/PngWriter.cpp, src/PngWriteSession.cpp:118-173):
+ * rgb[height][width][3] as a 16-bit RGB PNG with a "Title" text chunk when title is not empty. */
+int rth_write_png16(const char* path, const uint16_t* rgb, int32_t width, int32_t height, const char* title);
+
 #ifdef __cplusplus
 }
 #endif

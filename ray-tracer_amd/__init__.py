@@ -41,6 +41,7 @@ def host_lib():
         lib.rth_scene_settings.argtypes = [_C.c_void_p]
         lib.rth_scene_write.argtypes = [_C.c_void_p, _C.c_char_p]
         lib.rth_scene_free.argtypes = [_C.c_void_p]
+        lib.rth_write_png16.argtypes = [_C.c_char_p, _C.c_void_p, _C.c_int32, _C.c_int32, _C.c_char_p]
         _host = lib
     return _host
 

@@ -14,6 +14,8 @@
 #include <iostream>
 #include <limits>
 #include <stdexcept>
+#include <thread>
+#include <vector>
 
 namespace
 {
@@ -44,27 +46,52 @@ namespace Renderer
 
 void setDevice(int device) { g_device = device; }
 
+// Rows [begin, end) of a frame, split over the host's threads (at most 16); f(firstRow, lastRow).
+template <class F>
+void forRowBands(size_t height, F&& f)
+{
+    const size_t workers = std::max<size_t>(1, std::min<size_t>({16, std::thread::hardware_concurrency(), height}));
+    const size_t band = (height + workers - 1) / workers;
+    std::vector<std::thread> threads;
+    for (size_t w = 1; w < workers; ++w)
+    {
+        const size_t first = w * band, last = std::min(height, first + band);
+        if (first < last)
+        {
+            threads.emplace_back([&f, first, last]() { f(first, last); });
+        }
+    }
+    f(0, std::min(height, band));
+    for (std::thread& t : threads)
+    {
+        t.join();
+    }
+}
+
 void tonemapBufferToImage(const Buffer& buffer, Image& image, double photonsEmitted, double saturationLuminance)
 {
     (void)photonsEmitted;  // 1/N is applied upstream (reference src/Renderer.cpp:42)
     const size_t width = image.width(), height = image.height();
     const double invLmax = (saturationLuminance > 0.0) ? (1.0 / saturationLuminance) : 0.0;
-    for (size_t y = 0; y < height; ++y)
-    {
-        for (size_t x = 0; x < width; ++x)
+    // every pixel is independent: the reference's loop (src/Renderer.cpp:36-68), rows shared out over threads
+    forRowBands(height, [&](size_t firstRow, size_t lastRow) {
+        for (size_t y = firstRow; y < lastRow; ++y)
         {
-            const Color color = buffer.fetchColor(x, y);
-            const double exposedR = color.red * invLmax, exposedG = color.green * invLmax, exposedB = color.blue * invLmax;
-            const float gammaRed = std::pow(static_cast<float>(exposedR), 1.0f / Color::gamma);
-            const float gammaGreen = std::pow(static_cast<float>(exposedG), 1.0f / Color::gamma);
-            const float gammaBlue = std::pow(static_cast<float>(exposedB), 1.0f / Color::gamma);
-            Pixel p;
-            p.red = static_cast<std::uint16_t>(std::min(static_cast<int>(gammaRed * 65535), 65535));
-            p.green = static_cast<std::uint16_t>(std::min(static_cast<int>(gammaGreen * 65535), 65535));
-            p.blue = static_cast<std::uint16_t>(std::min(static_cast<int>(gammaBlue * 65535), 65535));
-            image.setPixel((width - 1) - x, (height - 1) - y, p);
+            for (size_t x = 0; x < width; ++x)
+            {
+                const Color color = buffer.fetchColor(x, y);
+                const double exposedR = color.red * invLmax, exposedG = color.green * invLmax, exposedB = color.blue * invLmax;
+                const float gammaRed = std::pow(static_cast<float>(exposedR), 1.0f / Color::gamma);
+                const float gammaGreen = std::pow(static_cast<float>(exposedG), 1.0f / Color::gamma);
+                const float gammaBlue = std::pow(static_cast<float>(exposedB), 1.0f / Color::gamma);
+                Pixel p;
+                p.red = static_cast<std::uint16_t>(std::min(static_cast<int>(gammaRed * 65535), 65535));
+                p.green = static_cast<std::uint16_t>(std::min(static_cast<int>(gammaGreen * 65535), 65535));
+                p.blue = static_cast<std::uint16_t>(std::min(static_cast<int>(gammaBlue * 65535), 65535));
+                image.setPixel((width - 1) - x, (height - 1) - y, p);
+            }
         }
-    }
+    });
 }
 
 RenderResult renderFrame(const LoadedScene& scene, ProgressCallback progress, PreviewCallback preview)
@@ -235,8 +262,10 @@ RenderResult renderFrame(const LoadedScene& scene, ProgressCallback progress, Pr
             cr.probe.depositsAccum = stats[2];
         }
         cr.gatherSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - gatherStart).count();
+        stage("gather");
         cr.buffer = std::make_shared<Buffer>(cam->width(), cam->height());
         check(rt_read_camera_buffer(tracer.ptr, static_cast<int32_t>(c), cr.buffer->data()));
+        stage("camera buffer to the host");
         if (preview && c == 0)
         {
             preview(*cr.buffer, 1.0, cam->saturationLuminance());
@@ -244,17 +273,28 @@ RenderResult renderFrame(const LoadedScene& scene, ProgressCallback progress, Pr
         cr.image = std::make_shared<Image>(cam->width(), cam->height());
         cr.image->clear();
         tonemapBufferToImage(*cr.buffer, *cr.image, photonsEmitted, cam->saturationLuminance());
-        double sum = 0.0;
-        for (size_t y = 0; y < cam->height(); ++y)
-        {
-            for (size_t x = 0; x < cam->width(); ++x)
+        // row sums in parallel, added in row order: the same value whatever the thread count
+        std::vector<double> rowSums(cam->height(), 0.0);
+        forRowBands(cam->height(), [&](size_t firstRow, size_t lastRow) {
+            for (size_t y = firstRow; y < lastRow; ++y)
             {
-                const Color col = cr.buffer->fetchColor(x, y);
-                sum += (static_cast<double>(col.red) + col.green + col.blue) / 3.0;
+                double rowSum = 0.0;
+                for (size_t x = 0; x < cam->width(); ++x)
+                {
+                    const Color col = cr.buffer->fetchColor(x, y);
+                    rowSum += (static_cast<double>(col.red) + col.green + col.blue) / 3.0;
+                }
+                rowSums[y] = rowSum;
             }
+        });
+        double sum = 0.0;
+        for (const double rowSum : rowSums)
+        {
+            sum += rowSum;
         }
         const double pixels = static_cast<double>(cam->width()) * static_cast<double>(cam->height());
         cr.meanLuminance = pixels > 0.0 ? sum / pixels : 0.0;
+        stage("tonemap and mean luminance");
         result.cameras.push_back(std::move(cr));
     }
     if (!result.cameras.empty())

@@ -4,6 +4,7 @@
 
 #include "Flatten.h"
 #include "FrameSetup.h"
+#include "PngWriter.h"
 #include "SceneLoader.h"
 #include "rt_scene_io.h"
 
@@ -65,6 +66,30 @@ int rth_frame_derive(const rt_scene* scene, double out[4])
     out[1] = d.cellSize;
     out[2] = d.minSplatRadius;
     out[3] = d.keepRadius;
+    return 0;
+}
+
+int rth_write_png16(const char* path, const uint16_t* rgb, int32_t width, int32_t height, const char* title)
+{
+    if (path == nullptr || rgb == nullptr || width <= 0 || height <= 0)
+    {
+        g_error = "rth_write_png16: bad arguments";
+        return 1;
+    }
+    Image image(static_cast<size_t>(width), static_cast<size_t>(height));
+    for (int32_t y = 0; y < height; ++y)
+    {
+        for (int32_t x = 0; x < width; ++x)
+        {
+            const uint16_t* p = rgb + 3 * (static_cast<size_t>(y) * static_cast<size_t>(width) + static_cast<size_t>(x));
+            image.setPixel(static_cast<size_t>(x), static_cast<size_t>(y), Pixel{p[0], p[1], p[2]});
+        }
+    }
+    if (!PngWriter::writeImage(path, image, title ? title : ""))
+    {
+        g_error = std::string("cannot write ") + path;
+        return 1;
+    }
     return 0;
 }
 

@@ -6,6 +6,7 @@
 #include "SceneLoader.h"
 
 #include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <filesystem>
 #include <fstream>
@@ -95,11 +96,17 @@ int main(int argc, char** argv)
             }
             const std::string fileName = scene.renderName + "." + std::to_string(frame) + ".png";
             const std::filesystem::path outputPath = scene.renderPath / fileName;
+            const auto writeStart = std::chrono::steady_clock::now();
             if (!PngWriter::writeImage(outputPath, *render.image, scene.renderName))
             {
                 throw std::runtime_error("cannot write " + outputPath.generic_string());
             }
             std::cout << "Wrote " << outputPath.generic_string() << std::endl;
+            if (std::getenv("RT_AMD_VERBOSE"))
+            {
+                std::fprintf(stderr, "[rt_amd] %-28s %8.1f ms\n", "PNG written",
+                             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - writeStart).count());
+            }
             for (size_t c = 1; c < render.cameras.size(); ++c)
             {
                 const CameraRender& cr = render.cameras[c];
