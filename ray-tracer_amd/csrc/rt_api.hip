@@ -1886,6 +1886,7 @@ int32_t rt_gather(rt_tracer* tracer, int32_t camera, double gather_cell_size, do
         DeviceArray<unsigned long long> keysIn, keysOut, stats, counts;
         DeviceArray<uint32_t> orderIn, orderOut;
         DeviceArray<unsigned char> scratch;
+        DeviceArray<float> sortedStore;
         uint64_t indexed = 0;
         if (n > 0)
         {
@@ -1908,15 +1909,20 @@ int32_t rt_gather(rt_tracer* tracer, int32_t camera, double gather_cell_size, do
                   "hipMemcpyAsync indexed");
             check(hipStreamSynchronize(tracer->stream), "hipStreamSynchronize");
             indexed = hostIndexed;
+            if (indexed > 0)
+            {
+                sortedStore.allocate(13 * indexed);
+                rtd::launchReorderStore(tracer->storeRecords.ptr, orderOut.ptr, indexed, sortedStore.ptr, tracer->stream);
+                check(hipGetLastError(), "store reorder launch");
+            }
         }
         stats.allocate(2);
         stats.zero(tracer->stream);
 
         rtd::GatherArgs args{};
         args.scene = tracer->view;
-        args.store = tracer->storeRecords.ptr;
+        args.store = sortedStore.ptr;
         args.keys = keysOut.ptr;
-        args.order = orderOut.ptr;
         args.indexed = indexed;
         args.invCellSize = 1.0 / cellSize;
         args.minGatherRadius = min_gather_radius;

@@ -153,9 +153,8 @@ void launchGatherWrite(const SceneView& scene, int32_t camera, int32_t stride, i
 struct GatherArgs
 {
     SceneView scene;
-    const float* store;                 // [records][13]
+    const float* store;                 // [records][13], IN KEY ORDER (launchReorderStore): row j belongs to keys[j]
     const unsigned long long* keys;     // packed cell of each record, ascending
-    const uint32_t* order;              // record index, same order as keys
     uint64_t indexed;                   // records that carry a valid key
     double invCellSize;
     double minGatherRadius;
@@ -176,6 +175,9 @@ size_t sortStoreKeys(void* scratch, size_t scratchBytes, const unsigned long lon
                      hipStream_t stream);
 // out[0] = number of leading keys below the "no cell" key (records of unpackable cells sort to the end)
 void launchCountIndexed(const unsigned long long* sortedKeys, uint64_t n, unsigned long long* out, hipStream_t stream);
+// sorted[j] = store[order[j]] for the first `indexed` positions: the gather then reads a cell's
+// records from consecutive rows instead of chasing the sort's permutation record by record.
+void launchReorderStore(const float* store, const uint32_t* order, uint64_t indexed, float* sorted, hipStream_t stream);
 void launchGather(const GatherArgs& args, hipStream_t stream);
 // Device-side build of the probe grid (rt_set_probes): see the kernels in rt_kernels.hip.
 struct ProbeBuild

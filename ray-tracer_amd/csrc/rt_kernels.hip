@@ -1159,6 +1159,14 @@ RT_DEV uint64_t lowerBound(const unsigned long long* keys, uint64_t n, unsigned 
     return lo;
 }
 
+__global__ void reorderStoreKernel(const float* store, const uint32_t* order, uint64_t floats, float* sorted)
+{
+    const uint64_t t = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (t >= floats) return;
+    const uint64_t j = t / 13, k = t % 13;
+    sorted[t] = store[13ull * order[j] + k];
+}
+
 __global__ void countIndexedKernel(const unsigned long long* keys, uint64_t n, unsigned long long* out)
 {
     out[0] = lowerBound(keys, n, kEmptyKey);
@@ -1213,7 +1221,19 @@ RT_DEV Color gatherRadiance(const GatherArgs& a, const GatherPoint& gp, unsigned
             const unsigned long long last = bySlab ? packCell(x1, y1, z) : packCell(x1, y, z);
             for (uint64_t j = lowerBound(a.keys, a.indexed, first); j < a.indexed; ++j)
             {
+                // The key and the whole 52-byte row are requested together, before any test looks at
+                // them: read field by field behind its test, a row costs up to five dependent round
+                // trips (key, position, time, normal, direction), and the loop is bound by exactly that.
+                // (Requesting the next row ahead of the work on this one gained 8 % on one scene and
+                // lost 14 % on another.)
+                typedef float Float4At4 __attribute__((ext_vector_type(4), aligned(4)));
+                const float* row = a.store + 13ull * j;
                 const unsigned long long key = a.keys[j];
+                Float4At4 q0 = *reinterpret_cast<const Float4At4*>(row);
+                Float4At4 q1 = *reinterpret_cast<const Float4At4*>(row + 4);
+                Float4At4 q2 = *reinterpret_cast<const Float4At4*>(row + 8);
+                float q3 = row[12];
+                asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3));  // the loads stay here, ahead of the branches
                 if (key > last)
                 {
                     break;
@@ -1226,7 +1246,7 @@ RT_DEV Color gatherRadiance(const GatherArgs& a, const GatherPoint& gp, unsigned
                         continue;
                     }
                 }
-                const float* rec = a.store + 13ull * a.order[j];
+                const float rec[13] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3};
                 const double ddx = static_cast<double>(rec[0]) - position.x;
                 const double ddy = static_cast<double>(rec[1]) - position.y;
                 const double ddz = static_cast<double>(rec[2]) - position.z;
@@ -1745,6 +1765,14 @@ size_t scanCounts(void* scratch, size_t scratchBytes, const uint32_t* counts, ui
 void launchCountIndexed(const unsigned long long* sortedKeys, uint64_t n, unsigned long long* out, hipStream_t stream)
 {
     hipLaunchKernelGGL(countIndexedKernel, dim3(1), dim3(1), 0, stream, sortedKeys, n, out);
+}
+
+void launchReorderStore(const float* store, const uint32_t* order, uint64_t indexed, float* sorted, hipStream_t stream)
+{
+    if (indexed == 0) return;
+    const uint64_t floats = 13ull * indexed;
+    hipLaunchKernelGGL(reorderStoreKernel, dim3(static_cast<unsigned int>((floats + 255) / 256)), dim3(256), 0, stream, store,
+                       order, floats, sorted);
 }
 
 void launchGather(const GatherArgs& args, hipStream_t stream)
