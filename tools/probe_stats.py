@@ -1,3 +1,5 @@
+"""Probes per keep-test cell of the given scenes (run on the GPU box from the repository root):
+    python tools/probe_stats.py MirrorKnot4k CornellBox"""
 import importlib, sys, numpy as np
 sys.path.insert(0, '.')
 rt = importlib.import_module("ray-tracer_amd")
