@@ -5,7 +5,7 @@ Run in the build container only (needs /root/reference to have been compiled wit
 reference's functions and dumps inputs + outputs; this script chooses scene sizes,
 subsamples rows to keep the fixtures small and packs them.
 
-    python oracle/make_golden.py
+    python oracle/make_golden.py [fixture ...]     (no names: every fixture)
 
 Fixtures written
     unit.npz      function-level vectors: triangle / bounds / sphere / quad / plane /
@@ -52,7 +52,24 @@ MANIFEST = {
                         "frame_time": 0.3},
     "probes_bombardment": {"scene": "scenes/MirrorBombardment-200M.json", "image": 96, "probe_sub_sample": 1,
                            "seed": 11},
+    # the scenes named for bit-exact hit ids and bounce counts, and the all-BSDF Cornell box
+    "walk_singlephoton": {"scene": "scenes/SinglePhotonVerify.json", "photons_per_light": 2000, "fetch_size": 700,
+                          "record": 2000, "seed": 21, "image": 48},
+    "walk_mirrordirect": {"scene": "scenes/MirrorDirectTest.json", "photons_per_light": 2000, "fetch_size": 700,
+                          "record": 2000, "seed": 22, "image": 48},
+    "walk_cbgmd": {"scene": "scenes/CornellBoxGlassMirrorDiffuse.json", "photons_per_light": 2000, "fetch_size": 700,
+                   "record": 2000, "seed": 23, "image": 48},
+    "walk_stochastic128": {"scene": "scenes/CBGMD_stochastic128.json", "photons_per_light": 1500, "fetch_size": 600,
+                           "record": 1500, "seed": 24, "image": 48},
+    # thin-lens cameras (explicit aperture; aperture from focal length / f-number) and an orthographic one
+    "probes_lens": {"scene": "tests/scenes/lens.json"},
+    "render_lens": {"scene": "tests/scenes/lens.json", "photons_per_light": 1500, "fetch_size": 50000},
 }
+
+WALKS = ("walk_furnace", "walk_mixed", "walk_animated", "walk_singlephoton", "walk_mirrordirect", "walk_cbgmd",
+         "walk_stochastic128")
+FRAMES = ("render_mixed", "render_mixed_tight", "render_animated", "render_lens")
+PROBES = ("probes_mixed", "probes_bombardment", "probes_animated", "probes_lens")
 
 
 def run(*args):
@@ -90,36 +107,46 @@ def write_scene(rt, entry, path):
 def main():
     rt = importlib.import_module("ray-tracer_amd")
     os.makedirs(GOLDEN, exist_ok=True)
+    chosen = set(sys.argv[1:])
+    unknown = chosen - set(MANIFEST) - {"unit"}
+    if unknown:
+        raise SystemExit(f"unknown fixtures: {sorted(unknown)}")
+
+    def wanted(key):
+        return not chosen or key in chosen
+
     with open(os.path.join(GOLDEN, "manifest.json"), "w") as f:
         json.dump(MANIFEST, f, indent=2, sort_keys=True)
 
     with tempfile.TemporaryDirectory() as tmp:
         # ---- function-level vectors ----
-        unit = os.path.join(tmp, "unit")
-        os.makedirs(unit)
-        run(REFDUMP, "unit", unit)
-        arrays = load_dir(unit)
-        packed = {}
-        keep_head = {"tri": 806}  # the shared-diagonal sweeps + back-face rows stay complete
-        # strides are coprime to every period the dump uses to vary its cases
-        stride = {"tri": 5, "bounds": 3, "sphere": 5, "quad": 7, "plane": 3, "quat": 2, "bsdf": 7, "eval": 7}
-        for name in stride:
-            a_in, a_out = arrays[f"{name}_in"], arrays[f"{name}_out"]
-            head = keep_head.get(name, 0)
-            rows = np.concatenate([np.arange(head), np.arange(head, a_in.shape[0], stride[name])])
-            packed[f"{name}_in"], packed[f"{name}_out"] = a_in[rows], a_out[rows]
-        np.savez_compressed(os.path.join(GOLDEN, "unit.npz"), **packed)
+        if wanted("unit"):
+            unit = os.path.join(tmp, "unit")
+            os.makedirs(unit)
+            run(REFDUMP, "unit", unit)
+            arrays = load_dir(unit)
+            packed = {}
+            keep_head = {"tri": 806}  # the shared-diagonal sweeps + back-face rows stay complete
+            # strides are coprime to every period the dump uses to vary its cases
+            stride = {"tri": 5, "bounds": 3, "sphere": 5, "quad": 7, "plane": 3, "quat": 2, "bsdf": 7, "eval": 7}
+            for name in stride:
+                a_in, a_out = arrays[f"{name}_in"], arrays[f"{name}_out"]
+                head = keep_head.get(name, 0)
+                rows = np.concatenate([np.arange(head), np.arange(head, a_in.shape[0], stride[name])])
+                packed[f"{name}_in"], packed[f"{name}_out"] = a_in[rows], a_out[rows]
+            np.savez_compressed(os.path.join(GOLDEN, "unit.npz"), **packed)
 
         # ---- emission ----
-        scene_path = os.path.join(tmp, "emit.rtsb")
-        write_scene(rt, MANIFEST["emit"], scene_path)
-        d = os.path.join(tmp, "emit")
-        os.makedirs(d)
-        run(REFDUMP, "emit", scene_path, d, str(MANIFEST["emit"]["n"]), str(MANIFEST["emit"]["seed"]))
-        np.savez_compressed(os.path.join(GOLDEN, "emit.npz"), **load_dir(d))
+        if wanted("emit"):
+            scene_path = os.path.join(tmp, "emit.rtsb")
+            write_scene(rt, MANIFEST["emit"], scene_path)
+            d = os.path.join(tmp, "emit")
+            os.makedirs(d)
+            run(REFDUMP, "emit", scene_path, d, str(MANIFEST["emit"]["n"]), str(MANIFEST["emit"]["seed"]))
+            np.savez_compressed(os.path.join(GOLDEN, "emit.npz"), **load_dir(d))
 
         # ---- photon walks ----
-        for key in ("walk_furnace", "walk_mixed", "walk_animated"):
+        for key in filter(wanted, WALKS):
             scene_path = os.path.join(tmp, key + ".rtsb")
             write_scene(rt, MANIFEST[key], scene_path)
             d = os.path.join(tmp, key)
@@ -130,18 +157,19 @@ def main():
             np.savez_compressed(os.path.join(GOLDEN, key + ".npz"), **arrays)
 
         # ---- full renderFrame on the furnace ----
-        scene_path = os.path.join(tmp, "render_furnace.rtsb")
-        write_scene(rt, MANIFEST["render_furnace"], scene_path)
-        d = os.path.join(tmp, "render_furnace")
-        os.makedirs(d)
-        run(REFDUMP, "render", scene_path, d)
-        arrays = load_dir(d)
-        keep = {k: arrays[k] for k in ("render_counters", "render_ledger", "render_crosscheck")}
-        keep["render_store_head"] = arrays["render_store_head"][:4096]
-        np.savez_compressed(os.path.join(GOLDEN, "render_furnace.npz"), **keep)
+        if wanted("render_furnace"):
+            scene_path = os.path.join(tmp, "render_furnace.rtsb")
+            write_scene(rt, MANIFEST["render_furnace"], scene_path)
+            d = os.path.join(tmp, "render_furnace")
+            os.makedirs(d)
+            run(REFDUMP, "render", scene_path, d)
+            arrays = load_dir(d)
+            keep = {k: arrays[k] for k in ("render_counters", "render_ledger", "render_crosscheck")}
+            keep["render_store_head"] = arrays["render_store_head"][:4096]
+            np.savez_compressed(os.path.join(GOLDEN, "render_furnace.npz"), **keep)
 
         # ---- whole frames in probe mode ----
-        for key in ("render_mixed", "render_mixed_tight", "render_animated"):
+        for key in filter(wanted, FRAMES):
             scene_path = os.path.join(tmp, key + ".rtsb")
             write_scene(rt, MANIFEST[key], scene_path)
             d = os.path.join(tmp, key)
@@ -157,7 +185,7 @@ def main():
             np.savez_compressed(os.path.join(GOLDEN, key + ".npz"), **keep)
 
         # ---- probe pass ----
-        for key in ("probes_mixed", "probes_bombardment", "probes_animated"):
+        for key in filter(wanted, PROBES):
             scene_path = os.path.join(tmp, key + ".rtsb")
             write_scene(rt, MANIFEST[key], scene_path)
             d = os.path.join(tmp, key)

@@ -86,7 +86,8 @@ def test_device_emission_matches_oracle_and_reference(rt, golden, manifest, scen
 def test_closest_hit_on_reference_rays(rt, golden, manifest, scene_opener):
     """Cast the reference walk's own rays: hit position/normal/distance bits, volume,
     triangle id and material equal the reference's (north star: bit-exact hit ids)."""
-    for key in ("walk_furnace", "walk_mixed"):
+    for key in ("walk_furnace", "walk_mixed", "walk_singlephoton", "walk_mirrordirect", "walk_cbgmd",
+                "walk_stochastic128"):
         g = golden(key)
         scene, tracer, orc = _open(rt, scene_opener, manifest[key])
         f64, i32 = g["walk_bounce_f64"], g["walk_bounce_i32"]
@@ -136,6 +137,7 @@ SCENES = {
     "multicam": {"scene": "scenes/MultiCameraTest.json", "photons_per_light": 5000},
     "singlephoton": {"scene": "scenes/SinglePhotonVerify.json", "photons_per_light": 5000},
     "mirrordirect": {"scene": "scenes/MirrorDirectTest.json", "photons_per_light": 5000},
+    "stochastic128": {"scene": "scenes/CBGMD_stochastic128.json", "photons_per_light": 6000},
     # keyframed plate, ball, knot and camera; photons are time-stamped across the shutter
     "animated": {"scene": "tests/scenes/animated.json", "photons_per_light": 3000, "frame_time": 0.3},
 }
@@ -221,7 +223,7 @@ def _sorted_records(store):
     return store[order]
 
 
-@pytest.mark.parametrize("name", ["mixed", "cbgmd", "bombardment", "animated"])
+@pytest.mark.parametrize("name", ["mixed", "cbgmd", "bombardment", "animated", "stochastic128"])
 def test_probe_sink_store_equals_oracle(rt, scene_opener, name):
     """Sink A: keep-test + BounceStore.  The store is a multiset (append order is a race in
     the reference too with > 1 worker): same records bit for bit after sorting; same counters."""
@@ -291,6 +293,9 @@ PROBE_SCENES = {
     "multicam": {"scene": "scenes/MultiCameraTest.json", "image": 96, "seed": 5},
     "shutter": {"scene": "tests/scenes/mixed.json", "shutter_time": 0.25, "camera_time_samples": 4},
     "animated": {"scene": "tests/scenes/animated.json", "frame_time": 0.3},
+    "stochastic128": {"scene": "scenes/CBGMD_stochastic128.json", "seed": 4},
+    # thin-lens cameras (aperture given, aperture from focal length and f-number) and an orthographic one
+    "lens": {"scene": "tests/scenes/lens.json"},
 }
 
 
@@ -395,6 +400,8 @@ GATHER_SCENES = {
     "bombardment": {"scene": "scenes/MirrorBombardment-200M.json", "photons_per_light": 400000, "image": 128,
                     "seed": 11},
     "animated": {"scene": "tests/scenes/animated.json", "photons_per_light": 2500, "frame_time": 0.3},
+    "stochastic128": {"scene": "scenes/CBGMD_stochastic128.json", "photons_per_light": 60000, "seed": 4},
+    "lens": {"scene": "tests/scenes/lens.json", "photons_per_light": 1500},
 }
 
 
@@ -489,7 +496,7 @@ def test_frame_statistically_equal_to_reference_frame(rt, golden, manifest, scen
     assert abs(float(device.sum()) - np.mean(energies)) <= 0.05 * np.mean(energies)
 
 
-@pytest.mark.parametrize("name", ["mixed", "multicam", "cbgmd", "animated"])
+@pytest.mark.parametrize("name", ["mixed", "multicam", "cbgmd", "animated", "stochastic128"])
 def test_splat_sink_equals_oracle(rt, scene_opener, name):
     """Sink B: direct camera splat (+ density grid).  Buffers are float-atomic sums, so they
     are compared to 1e-5 of the image's peak; counters are exact."""

@@ -78,7 +78,8 @@ def test_emission_vectors(rt, golden, manifest, scene_opener):
         assert_bits_equal(colors, g[f"emit_L{light}_color"], f"light {light} color")
 
 
-@pytest.mark.parametrize("key", ["walk_furnace", "walk_mixed", "walk_animated"])
+@pytest.mark.parametrize("key", ["walk_furnace", "walk_mixed", "walk_animated", "walk_singlephoton", "walk_mirrordirect",
+                                 "walk_cbgmd", "walk_stochastic128"])
 def test_seeded_walk_matches_reference(golden, manifest, scene_opener, key):
     """One seeded worker: every bounce's hit (position, normal, distance bits), volume,
     triangle id, material, photon power and every emitted ray equal the reference's."""
@@ -177,7 +178,7 @@ def test_decay_and_cap_termination(scene_opener):
     assert (r2["casts_valid"] == 1).all()
 
 
-@pytest.mark.parametrize("key", ["probes_mixed", "probes_bombardment", "probes_animated"])
+@pytest.mark.parametrize("key", ["probes_mixed", "probes_bombardment", "probes_animated", "probes_lens"])
 def test_probe_pass_matches_reference(golden, manifest, scene_opener, key):
     """ProbeGather::collectGatherPoints: every gather-point record (pixel, position, normal,
     view direction, material, throughput, path length, footprint, time, weight) and the three
@@ -215,7 +216,7 @@ def test_probe_pass_counter_mode_differs_only_in_stochastic_samples(manifest, sc
     assert same > 0.9 * common
 
 
-@pytest.mark.parametrize("key", ["render_mixed", "render_mixed_tight", "render_animated"])
+@pytest.mark.parametrize("key", ["render_mixed", "render_mixed_tight", "render_animated", "render_lens"])
 def test_whole_probe_mode_frame_matches_reference(golden, manifest, scene_opener, key):
     """Renderer::renderFrame in deterministic probe mode, stage by stage against the reference's
     own output: emitter deposits + photon deposits (the store, record for record), every
