@@ -165,6 +165,20 @@ int32_t rt_reset(rt_tracer* tracer);
 int32_t rt_trace(rt_tracer* tracer, const rt_trace_params* params);
 int32_t rt_synchronize(rt_tracer* tracer);
 
+/* rt_trace for callers that cannot allocate device memory (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc).  It has no counterpart in the reference.  Same
+ * pass, same sinks and counters as rt_trace, restricted to what needs no allocation: at most
+ * rt_trace_static_max_photons() photon ids per call (photon_count x lights; 1 Mi) — a larger range
+ * is refused with RT_ERR_ARGUMENT, split it over several calls —, record_photons == 0, one launch
+ * (no bounce-level queues) and no stage timings (rt_read_timings keeps failing with RT_ERR_STATE
+ * after it).  The emission-order list and the radix sort's work space live in a 32 MiB array that
+ * is part of the library's device code; every GPU the library runs on holds its copy until the
+ * process ends.  All tracers of one GPU share that array: calls that overlap on one GPU (two
+ * streams, two host threads) race, calls in sequence on one stream do not.  Sinks must have been
+ * set up (rt_set_probes / rt_set_splat: those allocate) and reset (rt_reset: does not) before. */
+int32_t rt_trace_static(rt_tracer* tracer, const rt_trace_params* params);
+uint64_t rt_trace_static_max_photons(void);
+
 /* Device time of the last rt_trace, from HIP events recorded on the tracer's stream around
  * its two stages: the emission-order sort of the photon ids (keys + radix sort; 0 when the
  * pass has 2^31 ids or more and is traced unsorted) and the trace kernel.  The reference reports one wall time for the whole pass

@@ -16,6 +16,7 @@
 #include <limits>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <unordered_map>
 #include <utility>
 #include <stdexcept>
@@ -121,6 +122,41 @@ double radians(double degrees) { return M_PI * (degrees / 180.0); }  // referenc
 
 }  // namespace
 
+// ---- scratch of rt_trace_static: a pass's emission-order list and the radix sort's work space in
+// memory that belongs to the library's code object, so that the call allocates nothing ----
+constexpr uint64_t kStaticMaxIds = 1ull << 20;             // photon ids of one rt_trace_static call at most
+constexpr size_t kStaticSortBytes = 16ull << 20;           // work space of the radix sort over that many pairs
+constexpr size_t kStaticHeaderBytes = 256;                 // [0] the pass's work counter
+constexpr size_t kStaticListBytes = kStaticMaxIds * sizeof(uint32_t);
+constexpr size_t kStaticScratchBytes = kStaticHeaderBytes + 4 * kStaticListBytes + kStaticSortBytes;
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+
+namespace
+{
+
+// Every GPU holds its own copy of `scratch` at its own address; in host code the array's name is
+// only a handle for hipGetSymbolAddress.  The address is looked up once per device (by rt_create,
+// with that device current) and everything after that uses the pointer.
+constexpr int kMaxDevices = 64;
+unsigned char* g_staticScratch[kMaxDevices] = {};
+std::mutex g_staticScratchMutex;
+
+unsigned char* staticScratchOf(int device)
+{
+    require(device >= 0 && device < kMaxDevices, "device index beyond the static scratch table");
+    std::lock_guard<std::mutex> lock(g_staticScratchMutex);
+    if (g_staticScratch[device] == nullptr)
+    {
+        void* address = nullptr;
+        check(hipGetSymbolAddress(&address, HIP_SYMBOL(scratch)), "hipGetSymbolAddress(scratch)");
+        require(address != nullptr, "static scratch has no device address");
+        g_staticScratch[device] = static_cast<unsigned char*>(address);
+    }
+    return g_staticScratch[device];
+}
+
+}  // namespace
+
 // bounce-level photon queues (see rt_trace)
 constexpr int kQueueLevels = 12;
 constexpr uint64_t kQueueCapacity = 48ull << 20;  // photons parked per level at most (4.5 GB per queue)
@@ -203,6 +239,8 @@ struct rt_tracer
 
     rtd::SceneView view{};
     int computeUnits = 0;
+    unsigned char* staticScratch = nullptr;  // this device's copy of `scratch` (rt_trace_static)
+    size_t staticSortBytes = 0;              // what the radix sort asks for at kStaticMaxIds pairs
 };
 
 namespace
@@ -715,10 +753,12 @@ rt_tracer::GatherCache& ensureGatherPoints(rt_tracer* tracer, int32_t camera)
     check(hipGetLastError(), "gather count launch");
     // offsets of every pixel's records: exclusive scan of the counts, on the device
     cache.offsets.allocate(static_cast<size_t>(pixels));
-    size_t scanBytes = rtd::scanCounts(nullptr, 0, cache.counts.ptr, cache.offsets.ptr, pixels, tracer->stream);
+    size_t scanBytes = 0;
+    check(rtd::scanCounts(nullptr, &scanBytes, cache.counts.ptr, cache.offsets.ptr, pixels, tracer->stream), "scan size query");
     DeviceArray<unsigned char> scanScratch;
     scanScratch.allocate(std::max<size_t>(scanBytes, 1));
-    rtd::scanCounts(scanScratch.ptr, scanBytes, cache.counts.ptr, cache.offsets.ptr, pixels, tracer->stream);
+    check(rtd::scanCounts(scanScratch.ptr, &scanBytes, cache.counts.ptr, cache.offsets.ptr, pixels, tracer->stream),
+          "gather offsets scan");
     check(hipGetLastError(), "gather offsets scan");
     unsigned long long hostStats[3] = {0, 0, 0};
     check(hipMemcpyAsync(hostStats, stats.ptr, sizeof(hostStats), hipMemcpyDeviceToHost, tracer->stream),
@@ -809,9 +849,10 @@ bool buildProbesOnDevice(rt_tracer* tracer, const double* probes, bool probesOnD
     {
         return false;
     }
-    size_t bytes = rtd::sortKeyPairs(nullptr, 0, keysIn.ptr, keysOut.ptr, orderIn.ptr, orderOut.ptr, n, stream);
+    size_t bytes = 0;
+    check(rtd::sortKeyPairs(nullptr, &bytes, keysIn.ptr, keysOut.ptr, orderIn.ptr, orderOut.ptr, n, stream), "sort size query");
     scratch.allocate(std::max<size_t>(bytes, 1));
-    rtd::sortKeyPairs(scratch.ptr, bytes, keysIn.ptr, keysOut.ptr, orderIn.ptr, orderOut.ptr, n, stream);
+    check(rtd::sortKeyPairs(scratch.ptr, &bytes, keysIn.ptr, keysOut.ptr, orderIn.ptr, orderOut.ptr, n, stream), "probe cell sort");
     rtd::launchCountRuns(keysOut.ptr, n, scalars.ptr, stream);
     unsigned long long cellCount = 0;
     check(hipMemcpyAsync(&cellCount, scalars.ptr, sizeof(cellCount), hipMemcpyDeviceToHost, stream), "hipMemcpyAsync runs");
@@ -841,9 +882,12 @@ bool buildProbesOnDevice(rt_tracer* tracer, const double* probes, bool probesOnD
     bitsIn.allocate(candidates);
     bitsOut.allocate(candidates);
     rtd::launchNeighbourKeys(keysOut.ptr, n, nearIn.ptr, bitsIn.ptr, scalars.ptr + 1, stream);
-    bytes = rtd::sortKeyPairs(nullptr, 0, nearIn.ptr, nearOut.ptr, bitsIn.ptr, bitsOut.ptr, candidates, stream);
+    bytes = 0;
+    check(rtd::sortKeyPairs(nullptr, &bytes, nearIn.ptr, nearOut.ptr, bitsIn.ptr, bitsOut.ptr, candidates, stream),
+          "sort size query");
     if (scratch.count < bytes) scratch.allocate(bytes);
-    rtd::sortKeyPairs(scratch.ptr, bytes, nearIn.ptr, nearOut.ptr, bitsIn.ptr, bitsOut.ptr, candidates, stream);
+    check(rtd::sortKeyPairs(scratch.ptr, &bytes, nearIn.ptr, nearOut.ptr, bitsIn.ptr, bitsOut.ptr, candidates, stream),
+          "neighbour key sort");
     check(hipMemsetAsync(scalars.ptr, 0, sizeof(unsigned long long), stream), "hipMemsetAsync");
     rtd::launchCountRuns(nearOut.ptr, candidates, scalars.ptr, stream);
     unsigned long long nearCount = 0;
@@ -1141,6 +1185,10 @@ int32_t rt_create(const rt_scene* scene, int32_t device, rt_tracer** out)
         hipDeviceProp_t prop{};
         check(hipGetDeviceProperties(&prop, device), "hipGetDeviceProperties");
         t->computeUnits = prop.multiProcessorCount;
+        t->staticScratch = staticScratchOf(device);
+        check(rtd::sortEmissionPairs(nullptr, &t->staticSortBytes, nullptr, nullptr, nullptr, nullptr, kStaticMaxIds,
+                                     static_cast<int>(std::max<int64_t>(1, t->lightCount)), nullptr),
+              "sort size query");
         resetState(t.get());
         check(hipStreamSynchronize(t->stream), "hipStreamSynchronize");
         *out = t.release();
@@ -1446,42 +1494,84 @@ int32_t rt_reset(rt_tracer* tracer)
     });
 }
 
+namespace
+{
+
+// The photon range of a pass: indices [first, first + count) of every light, cut to the budget.
+// photon_count == 0 asks for everything from first_photon on (rt_amd.h).
+void resolveRange(const rt_tracer* tracer, const rt_trace_params* params, uint64_t* first, uint64_t* count)
+{
+    const uint64_t total = tracer->settings.photons_per_light;
+    *first = std::min<uint64_t>(params->first_photon, total);
+    *count = params->photon_count;
+    if (*count == 0 || *count > total - *first)
+    {
+        *count = total - *first;
+    }
+    const uint64_t lights = static_cast<uint64_t>(std::max<int64_t>(1, tracer->lightCount));
+    require(*count <= std::numeric_limits<uint64_t>::max() / lights, "photon range too large");
+}
+
+void requireSink(const rt_tracer* tracer, const rt_trace_params* params)
+{
+    if (params->sink_mode == RT_SINK_PROBE && !tracer->probesSet)
+    {
+        throw ApiError(RT_ERR_STATE, "rt_set_probes must be called before tracing with RT_SINK_PROBE");
+    }
+    if (params->sink_mode == RT_SINK_SPLAT && !tracer->splatSet)
+    {
+        throw ApiError(RT_ERR_STATE, "rt_set_splat must be called before tracing with RT_SINK_SPLAT");
+    }
+    require(params->sink_mode >= RT_SINK_NONE && params->sink_mode <= RT_SINK_SPLAT, "unknown sink mode");
+}
+
+// Everything of a pass's kernel arguments that does not depend on how its work is scheduled.
+rtd::TraceArgs passArguments(const rt_tracer* tracer, const rt_trace_params* params, uint64_t first, uint64_t count)
+{
+    rtd::TraceArgs args{};
+    args.scene = tracer->view;
+    args.probes = tracer->probeView;
+    args.store.records = tracer->storeRecords.ptr;
+    args.store.cursor = tracer->scalars.ptr + 1;
+    args.store.capacity = tracer->storeCapacity;
+    args.density = tracer->densityView;
+    args.counters = tracer->counters.ptr;
+    args.workCounter = tracer->scalars.ptr;
+    args.firstPhoton = first;
+    args.photonCount = count;
+    args.totalWork = count * static_cast<uint64_t>(tracer->lightCount);
+    args.minSplatRadius = tracer->minSplatRadius;
+    args.sinkMode = params->sink_mode;
+    return args;
+}
+
+// Run lengths of one launch over `work` items: every resident wave should see several runs, so
+// small launches use short runs, and the last sixteenth of a launch goes out in pieces a quarter
+// as long so that the waves end together.  Returns the number of blocks to launch.
+int scheduleLaunch(rtd::TraceArgs& launch, uint64_t work, int residentBlocks, bool ordered)
+{
+    const uint64_t waves = static_cast<uint64_t>(residentBlocks) * 4;
+    uint64_t chunk = work / (waves * 4);
+    // parked photons are in no particular order: short runs, for balance
+    chunk = std::min<uint64_t>(ordered ? 4096 : 256, std::max<uint64_t>(64, chunk)) & ~63ull;
+    launch.chunk = static_cast<uint32_t>(chunk);
+    launch.tailChunk = static_cast<uint32_t>(std::max<uint64_t>(64, (chunk / 4) & ~63ull));
+    launch.fullClaims = (work - work / 16) / chunk;
+    const uint64_t wavesNeeded = (work + 63) / 64;
+    return std::max(1, static_cast<int>(std::min<uint64_t>(static_cast<uint64_t>(residentBlocks), (wavesNeeded + 3) / 4)));
+}
+
+}  // namespace
+
 int32_t rt_trace(rt_tracer* tracer, const rt_trace_params* params)
 {
     return guarded([&]() {
         require(tracer != nullptr && params != nullptr, "null argument");
         activate(tracer);
-        const uint64_t total = tracer->settings.photons_per_light;
-        uint64_t first = std::min<uint64_t>(params->first_photon, total);
-        uint64_t count = params->photon_count;
-        if (count == 0 || first + count > total)
-        {
-            count = total - first;
-        }
-        if (params->sink_mode == RT_SINK_PROBE && !tracer->probesSet)
-        {
-            throw ApiError(RT_ERR_STATE, "rt_set_probes must be called before tracing with RT_SINK_PROBE");
-        }
-        if (params->sink_mode == RT_SINK_SPLAT && !tracer->splatSet)
-        {
-            throw ApiError(RT_ERR_STATE, "rt_set_splat must be called before tracing with RT_SINK_SPLAT");
-        }
-        require(params->sink_mode >= RT_SINK_NONE && params->sink_mode <= RT_SINK_SPLAT, "unknown sink mode");
-
-        rtd::TraceArgs args{};
-        args.scene = tracer->view;
-        args.probes = tracer->probeView;
-        args.store.records = tracer->storeRecords.ptr;
-        args.store.cursor = tracer->scalars.ptr + 1;
-        args.store.capacity = tracer->storeCapacity;
-        args.density = tracer->densityView;
-        args.counters = tracer->counters.ptr;
-        args.workCounter = tracer->scalars.ptr;
-        args.firstPhoton = first;
-        args.photonCount = count;
-        args.totalWork = count * static_cast<uint64_t>(tracer->lightCount);
-        args.minSplatRadius = tracer->minSplatRadius;
-        args.sinkMode = params->sink_mode;
+        uint64_t first = 0, count = 0;
+        resolveRange(tracer, params, &first, &count);
+        requireSink(tracer, params);
+        rtd::TraceArgs args = passArguments(tracer, params, first, count);
 
         const int32_t maxBounces = tracer->settings.bounce_threshold + 1;
         const uint64_t record = std::min<uint64_t>(params->record_photons, args.totalWork);
@@ -1534,11 +1624,14 @@ int32_t rt_trace(rt_tracer* tracer, const rt_trace_params* params)
             }
             rtd::launchEmissionKeys(args, tracer->sortKeysIn.ptr, tracer->sortIds.ptr, tracer->stream);
             const int lights = static_cast<int>(tracer->lightCount);
-            const size_t bytes = rtd::sortEmissionPairs(nullptr, 0, tracer->sortKeysIn.ptr, tracer->sortKeysOut.ptr,
-                                                        tracer->sortIds.ptr, tracer->sortOrder.ptr, n, lights, tracer->stream);
+            size_t bytes = 0;
+            check(rtd::sortEmissionPairs(nullptr, &bytes, tracer->sortKeysIn.ptr, tracer->sortKeysOut.ptr, tracer->sortIds.ptr,
+                                         tracer->sortOrder.ptr, n, lights, tracer->stream),
+                  "sort size query");
             if (tracer->sortScratch.count < bytes) tracer->sortScratch.allocate(bytes);
-            rtd::sortEmissionPairs(tracer->sortScratch.ptr, bytes, tracer->sortKeysIn.ptr, tracer->sortKeysOut.ptr,
-                                   tracer->sortIds.ptr, tracer->sortOrder.ptr, n, lights, tracer->stream);
+            check(rtd::sortEmissionPairs(tracer->sortScratch.ptr, &bytes, tracer->sortKeysIn.ptr, tracer->sortKeysOut.ptr,
+                                         tracer->sortIds.ptr, tracer->sortOrder.ptr, n, lights, tracer->stream),
+                  "emission sort");
             check(hipGetLastError(), "emission sort");
             args.emissionOrder = tracer->sortOrder.ptr;
         }
@@ -1596,20 +1689,8 @@ int32_t rt_trace(rt_tracer* tracer, const rt_trace_params* params)
                 launch.queueOutCount = counts + 2 * level;
                 launch.queueOutCapacity = capacity;
             }
-            // every resident wave should see several runs: small launches use short runs
-            {
-                const uint64_t waves = static_cast<uint64_t>(residentBlocks) * 4;
-                uint64_t chunk = work / (waves * 4);
-                // parked photons are in no particular order: short runs, for balance
-                chunk = std::min<uint64_t>(level > 0 ? 256 : 4096, std::max<uint64_t>(64, chunk)) & ~63ull;
-                launch.chunk = static_cast<uint32_t>(chunk);
-                // the last sixteenth of a launch goes out in pieces a quarter as long
-                launch.tailChunk = static_cast<uint32_t>(std::max<uint64_t>(64, (chunk / 4) & ~63ull));
-                launch.fullClaims = (work - work / 16) / chunk;
-            }
-            const uint64_t wavesNeeded = (work + 63) / 64;
-            const int blocks = static_cast<int>(std::min<uint64_t>(static_cast<uint64_t>(residentBlocks), (wavesNeeded + 3) / 4));
-            rtd::launchTrace(launch, std::max(1, blocks), 256, tracer->stream);
+            const int blocks = scheduleLaunch(launch, work, residentBlocks, level == 0);
+            rtd::launchTrace(launch, blocks, 256, tracer->stream);
             check(hipGetLastError(), "trace launch");
             if (level == levels)
             {
@@ -1627,6 +1708,62 @@ int32_t rt_trace(rt_tracer* tracer, const rt_trace_params* params)
         }
         check(hipEventRecord(tracer->stageEvents[2], tracer->stream), "hipEventRecord");
         tracer->timed = true;
+    });
+}
+
+uint64_t rt_trace_static_max_photons(void) { return kStaticMaxIds; }
+
+int32_t rt_trace_static(rt_tracer* tracer, const rt_trace_params* params)
+{
+    return guarded([&]() {
+        require(tracer != nullptr && params != nullptr, "null argument");
+        activate(tracer);
+        uint64_t first = 0, count = 0;
+        resolveRange(tracer, params, &first, &count);
+        requireSink(tracer, params);
+        require(params->record_photons == 0, "rt_trace_static keeps no per-photon records (record_photons must be 0)");
+        rtd::TraceArgs args = passArguments(tracer, params, first, count);
+        if (args.totalWork > kStaticMaxIds)
+        {
+            throw ApiError(RT_ERR_ARGUMENT, "rt_trace_static: " + std::to_string(args.totalWork) +
+                                                " photons (photon_count x lights) exceed the static scratch's " +
+                                                std::to_string(kStaticMaxIds) + "; split the range or use rt_trace");
+        }
+        if (tracer->staticSortBytes > kStaticSortBytes)
+        {
+            throw ApiError(RT_ERR_STATE, "rt_trace_static: the radix sort asks for " + std::to_string(tracer->staticSortBytes) +
+                                             " bytes of work space, the static scratch reserves " +
+                                             std::to_string(kStaticSortBytes));
+        }
+        tracer->recordPhotons = 0;  // the buffers of an earlier rt_trace stay allocated and are not read
+        tracer->timed = false;
+        if (args.totalWork == 0)
+        {
+            return;
+        }
+        // the device's copy of `scratch`: work counter, four id / key lists, the sort's work space
+        unsigned char* base = tracer->staticScratch;
+        unsigned long long* workCounter = reinterpret_cast<unsigned long long*>(base);
+        uint32_t* keysIn = reinterpret_cast<uint32_t*>(base + kStaticHeaderBytes);
+        uint32_t* keysOut = reinterpret_cast<uint32_t*>(base + kStaticHeaderBytes + kStaticListBytes);
+        uint32_t* idsIn = reinterpret_cast<uint32_t*>(base + kStaticHeaderBytes + 2 * kStaticListBytes);
+        uint32_t* idsOut = reinterpret_cast<uint32_t*>(base + kStaticHeaderBytes + 3 * kStaticListBytes);
+        unsigned char* sortSpace = base + kStaticHeaderBytes + 4 * kStaticListBytes;
+        // the array keeps the last call's contents: the counter has to start at zero, the lists are
+        // written before they are read
+        check(hipMemsetAsync(workCounter, 0, kStaticHeaderBytes, tracer->stream), "hipMemsetAsync");
+        args.workCounter = workCounter;
+        rtd::launchEmissionKeys(args, keysIn, idsIn, tracer->stream);
+        size_t bytes = kStaticSortBytes;
+        check(rtd::sortEmissionPairs(sortSpace, &bytes, keysIn, keysOut, idsIn, idsOut, args.totalWork,
+                                     static_cast<int>(tracer->lightCount), tracer->stream),
+              "emission sort");
+        check(hipGetLastError(), "emission sort");
+        args.emissionOrder = idsOut;
+        const int residentBlocks = tracer->computeUnits * rtd::traceBlocksPerCu(args);
+        const int blocks = scheduleLaunch(args, args.totalWork, residentBlocks, true);
+        rtd::launchTrace(args, blocks, 256, tracer->stream);
+        check(hipGetLastError(), "trace launch");
     });
 }
 
@@ -1896,10 +2033,13 @@ int32_t rt_gather(rt_tracer* tracer, int32_t camera, double gather_cell_size, do
             orderOut.allocate(n);
             rtd::launchStoreKeys(tracer->storeRecords.ptr, n, 1.0 / cellSize, keysIn.ptr, orderIn.ptr, tracer->stream);
             check(hipGetLastError(), "store keys launch");
-            const size_t bytes =
-                rtd::sortStoreKeys(nullptr, 0, keysIn.ptr, keysOut.ptr, orderIn.ptr, orderOut.ptr, n, tracer->stream);
+            size_t bytes = 0;
+            check(rtd::sortStoreKeys(nullptr, &bytes, keysIn.ptr, keysOut.ptr, orderIn.ptr, orderOut.ptr, n, tracer->stream),
+                  "sort size query");
             scratch.allocate(bytes > 0 ? bytes : 1);
-            rtd::sortStoreKeys(scratch.ptr, bytes, keysIn.ptr, keysOut.ptr, orderIn.ptr, orderOut.ptr, n, tracer->stream);
+            check(rtd::sortStoreKeys(scratch.ptr, &bytes, keysIn.ptr, keysOut.ptr, orderIn.ptr, orderOut.ptr, n,
+                                     tracer->stream),
+                  "store sort");
             check(hipGetLastError(), "store sort");
             // records whose cell could not be packed sort to the end; find where they start
             counts.allocate(1);

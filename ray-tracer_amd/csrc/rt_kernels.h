@@ -126,12 +126,13 @@ struct TraceArgs
 };
 
 void launchTrace(const TraceArgs& args, int blocks, int threads, hipStream_t stream);
-// Whole-pass emission order: keys and ids of every photon of the pass, then a radix sort of the pairs
-// (returns the scratch bytes needed when scratch is null).
+// Whole-pass emission order: keys and ids of every photon of the pass, then a radix sort of the pairs.
+// The sorts and the scan below follow hipCUB's convention: with a null `scratch` nothing runs and
+// *scratchBytes receives the work space the call needs; the library's status is returned.
 void launchEmissionKeys(const TraceArgs& args, uint32_t* keys, uint32_t* ids, hipStream_t stream);
 
-size_t sortEmissionPairs(void* scratch, size_t scratchBytes, const uint32_t* keysIn, uint32_t* keysOut, const uint32_t* idsIn,
-                         uint32_t* idsOut, uint64_t n, int lightCount, hipStream_t stream);
+hipError_t sortEmissionPairs(void* scratch, size_t* scratchBytes, const uint32_t* keysIn, uint32_t* keysOut,
+                             const uint32_t* idsIn, uint32_t* idsOut, uint64_t n, int lightCount, hipStream_t stream);
 void launchCastRays(const SceneView& scene, int64_t n, const double* rays, double selfHit, double* outF64,
                     int32_t* outI32, hipStream_t stream);
 void launchEmit(const SceneView& scene, int32_t light, int64_t n, const double* draws5, uint64_t totalPhotons,
@@ -168,11 +169,10 @@ struct GatherArgs
 };
 void launchStoreKeys(const float* store, uint64_t n, double invCellSize, unsigned long long* keys, uint32_t* order,
                      hipStream_t stream);
-// Stable ascending sort of (keys, order); returns the byte size of the scratch it needs when
-// `scratch` is null.
-size_t sortStoreKeys(void* scratch, size_t scratchBytes, const unsigned long long* keysIn,
-                     unsigned long long* keysOut, const uint32_t* orderIn, uint32_t* orderOut, uint64_t n,
-                     hipStream_t stream);
+// Stable ascending sort of (keys, order).
+hipError_t sortStoreKeys(void* scratch, size_t* scratchBytes, const unsigned long long* keysIn,
+                         unsigned long long* keysOut, const uint32_t* orderIn, uint32_t* orderOut, uint64_t n,
+                         hipStream_t stream);
 // out[0] = number of leading keys below the "no cell" key (records of unpackable cells sort to the end)
 void launchCountIndexed(const unsigned long long* sortedKeys, uint64_t n, unsigned long long* out, hipStream_t stream);
 // sorted[j] = store[order[j]] for the first `indexed` positions: the gather then reads a cell's
@@ -189,8 +189,9 @@ struct ProbeBuild
     uint32_t* order;               // [n] probe index
 };
 void launchProbeKeys(const ProbeBuild& b, uint32_t* unpackable, hipStream_t stream);
-// offsets[i] = counts[0] + ... + counts[i - 1] (returns the scratch bytes needed when scratch is null)
-size_t scanCounts(void* scratch, size_t scratchBytes, const uint32_t* counts, uint64_t* offsets, int64_t n, hipStream_t stream);
+// offsets[i] = counts[0] + ... + counts[i - 1]
+hipError_t scanCounts(void* scratch, size_t* scratchBytes, const uint32_t* counts, uint64_t* offsets, int64_t n,
+                      hipStream_t stream);
 // ProbeGather::depositEmitters for one emitter patch: a countU x countV grid of cell-centred
 // samples over the patch (inside the disc for a disc).
 struct EmitterGrid
@@ -207,8 +208,8 @@ void launchEmitterDeposit(const EmitterGrid& grid, const ProbeView& probes, cons
                           unsigned long long* kept, hipStream_t stream);
 void launchProbePositions(const GatherPoint* points, uint64_t n, double* positions, hipStream_t stream);
 // stable ascending sort of (keys, order) pairs of any length below 2^31
-size_t sortKeyPairs(void* scratch, size_t scratchBytes, const unsigned long long* keysIn, unsigned long long* keysOut,
-                    const uint32_t* orderIn, uint32_t* orderOut, uint64_t n, hipStream_t stream);
+hipError_t sortKeyPairs(void* scratch, size_t* scratchBytes, const unsigned long long* keysIn, unsigned long long* keysOut,
+                        const uint32_t* orderIn, uint32_t* orderOut, uint64_t n, hipStream_t stream);
 void launchCountRuns(const unsigned long long* sortedKeys, uint64_t n, unsigned long long* runs, hipStream_t stream);
 void launchProbeTable(const unsigned long long* sortedKeys, const uint32_t* sortedOrder, const double* points, uint64_t n,
                       int64_t* slotKey, uint32_t* slotStart, uint32_t* slotCount, PackedCell* packedCells,

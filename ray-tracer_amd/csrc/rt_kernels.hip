@@ -1653,15 +1653,13 @@ void launchEmissionKeys(const TraceArgs& args, uint32_t* keys, uint32_t* ids, hi
                        ids);
 }
 
-size_t sortEmissionPairs(void* scratch, size_t scratchBytes, const uint32_t* keysIn, uint32_t* keysOut, const uint32_t* idsIn,
-                         uint32_t* idsOut, uint64_t n, int lightCount, hipStream_t stream)
+hipError_t sortEmissionPairs(void* scratch, size_t* scratchBytes, const uint32_t* keysIn, uint32_t* keysOut,
+                             const uint32_t* idsIn, uint32_t* idsOut, uint64_t n, int lightCount, hipStream_t stream)
 {
-    size_t bytes = scratchBytes;
     int lightBits = 0;
     while ((1 << lightBits) < lightCount && lightBits < 8) ++lightBits;
-    (void)hipcub::DeviceRadixSort::SortPairs(scratch, bytes, keysIn, keysOut, idsIn, idsOut, static_cast<int>(n), 0,
-                                             2 * kGlobalAxisBits + lightBits, stream);
-    return bytes;
+    return hipcub::DeviceRadixSort::SortPairs(scratch, *scratchBytes, keysIn, keysOut, idsIn, idsOut, static_cast<int>(n), 0,
+                                              2 * kGlobalAxisBits + lightBits, stream);
 }
 
 void launchTrace(const TraceArgs& args, int blocks, int threads, hipStream_t stream)
@@ -1735,15 +1733,13 @@ void launchStoreKeys(const float* store, uint64_t n, double invCellSize, unsigne
                        invCellSize, keys, order);
 }
 
-size_t sortStoreKeys(void* scratch, size_t scratchBytes, const unsigned long long* keysIn,
-                     unsigned long long* keysOut, const uint32_t* orderIn, uint32_t* orderOut, uint64_t n,
-                     hipStream_t stream)
+hipError_t sortStoreKeys(void* scratch, size_t* scratchBytes, const unsigned long long* keysIn,
+                         unsigned long long* keysOut, const uint32_t* orderIn, uint32_t* orderOut, uint64_t n,
+                         hipStream_t stream)
 {
-    size_t bytes = scratchBytes;
     // radix sort is stable: records of one cell keep their store order
-    (void)hipcub::DeviceRadixSort::SortPairs(scratch, bytes, keysIn, keysOut, orderIn, orderOut, static_cast<int>(n), 0,
-                                             64, stream);
-    return bytes;
+    return hipcub::DeviceRadixSort::SortPairs(scratch, *scratchBytes, keysIn, keysOut, orderIn, orderOut,
+                                              static_cast<int>(n), 0, 64, stream);
 }
 
 namespace
@@ -1754,12 +1750,11 @@ struct WidenCount
 };
 }  // namespace
 
-size_t scanCounts(void* scratch, size_t scratchBytes, const uint32_t* counts, uint64_t* offsets, int64_t n, hipStream_t stream)
+hipError_t scanCounts(void* scratch, size_t* scratchBytes, const uint32_t* counts, uint64_t* offsets, int64_t n,
+                      hipStream_t stream)
 {
-    size_t bytes = scratchBytes;
     hipcub::TransformInputIterator<uint64_t, WidenCount, const uint32_t*> wide(counts, WidenCount());
-    (void)hipcub::DeviceScan::ExclusiveSum(scratch, bytes, wide, offsets, static_cast<int>(n), stream);
-    return bytes;
+    return hipcub::DeviceScan::ExclusiveSum(scratch, *scratchBytes, wide, offsets, static_cast<int>(n), stream);
 }
 
 void launchCountIndexed(const unsigned long long* sortedKeys, uint64_t n, unsigned long long* out, hipStream_t stream)
@@ -1808,13 +1803,11 @@ void launchProbeKeys(const ProbeBuild& b, uint32_t* unpackable, hipStream_t stre
     hipLaunchKernelGGL(probeKeysKernel, dim3(gridFor(static_cast<int64_t>(b.n))), dim3(256), 0, stream, b, unpackable);
 }
 
-size_t sortKeyPairs(void* scratch, size_t scratchBytes, const unsigned long long* keysIn, unsigned long long* keysOut,
-                    const uint32_t* orderIn, uint32_t* orderOut, uint64_t n, hipStream_t stream)
+hipError_t sortKeyPairs(void* scratch, size_t* scratchBytes, const unsigned long long* keysIn, unsigned long long* keysOut,
+                        const uint32_t* orderIn, uint32_t* orderOut, uint64_t n, hipStream_t stream)
 {
-    size_t bytes = scratchBytes;
-    (void)hipcub::DeviceRadixSort::SortPairs(scratch, bytes, keysIn, keysOut, orderIn, orderOut, static_cast<int>(n), 0,
-                                             64, stream);
-    return bytes;
+    return hipcub::DeviceRadixSort::SortPairs(scratch, *scratchBytes, keysIn, keysOut, orderIn, orderOut,
+                                              static_cast<int>(n), 0, 64, stream);
 }
 
 void launchCountRuns(const unsigned long long* sortedKeys, uint64_t n, unsigned long long* runs, hipStream_t stream)

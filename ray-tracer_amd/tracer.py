@@ -47,6 +47,8 @@ _SIGNATURES = {
     "rt_bind_camera_buffer": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p]),
     "rt_reset": (C.c_int32, [C.c_void_p]),
     "rt_trace": (C.c_int32, [C.c_void_p, C.POINTER(RtTraceParams)]),
+    "rt_trace_static": (C.c_int32, [C.c_void_p, C.POINTER(RtTraceParams)]),
+    "rt_trace_static_max_photons": (C.c_uint64, []),
     "rt_synchronize": (C.c_int32, [C.c_void_p]),
     "rt_read_timings": (C.c_int32, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "rt_read_counters": (C.c_int32, [C.c_void_p, C.POINTER(RtCounters)]),
@@ -183,6 +185,12 @@ class Tracer:
     def trace(self, sink_mode=SINK_NONE, first_photon=0, photon_count=0, record_photons=0):
         params = RtTraceParams(sink_mode, 0, first_photon, photon_count, record_photons)
         _check(tracer_lib().rt_trace(self._handle, C.byref(params)))
+
+    def trace_static(self, sink_mode=SINK_NONE, first_photon=0, photon_count=0):
+        """The pass through the entry point that allocates nothing (at most
+        rt_trace_static_max_photons() ids per call)."""
+        params = RtTraceParams(sink_mode, 0, first_photon, photon_count, 0)
+        _check(tracer_lib().rt_trace_static(self._handle, C.byref(params)))
 
     def synchronize(self):
         _check(tracer_lib().rt_synchronize(self._handle))
