@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <array>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -17,6 +18,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <numeric>
 #include <unordered_map>
 #include <utility>
 #include <stdexcept>
@@ -171,6 +173,7 @@ struct rt_tracer
     int64_t lightCount = 0;
 
     DeviceArray<rtd::Volume> volumes;
+    DeviceArray<unsigned char> cacheImage;
     DeviceArray<rtd::Node> nodes;
     DeviceArray<double> triRec, triNrm;
     DeviceArray<int32_t> triId;
@@ -236,6 +239,13 @@ struct rt_tracer
         uint64_t stats[3] = {0, 0, 0};
     };
     std::vector<std::unique_ptr<GatherCache>> gatherCache;
+    struct GatherSpace  // work space of rt_gather, kept between calls
+    {
+        DeviceArray<unsigned long long> keysIn, keysOut, stats;
+        DeviceArray<uint32_t> orderIn, orderOut;
+        DeviceArray<unsigned char> scratch;
+        DeviceArray<float> sortedStore;
+    } gatherSpace;
 
     rtd::SceneView view{};
     int computeUnits = 0;
@@ -303,7 +313,8 @@ void buildScene(rt_tracer* t, const rt_scene* scene)
     struct MeshSpan
     {
         int32_t nodeBase, nodeCount;
-        int64_t triBase;
+        int64_t triBase, triCount;
+        int32_t ldsNodeCount = 0, ldsNodeOffset = 0, ldsTriOffset = -1;
         double extent;
         double lo[3], hi[3];  // object-space bounds
     };
@@ -331,7 +342,7 @@ void buildScene(rt_tracer* t, const rt_scene* scene)
         const double pad = 4e-6 * sceneScale;
         const rtbvh::FlatMesh flat =
             rtbvh::buildSurfaceArea(pos, mesh.triangle_count, rtbvh::build(pos, mesh.triangle_count), pad, leafSize);
-        const rtbvh::WideMesh wide = rtbvh::widen(flat);
+        const rtbvh::WideMesh wide = rtbvh::breadthFirst(rtbvh::widen(flat));
         maxDepth = std::max(maxDepth, wide.pushDepth);
         if (std::getenv("RT_AMD_VERBOSE"))
         {
@@ -343,6 +354,7 @@ void buildScene(rt_tracer* t, const rt_scene* scene)
         span.nodeBase = static_cast<int32_t>(nodes.size());
         span.nodeCount = static_cast<int32_t>(wide.nodes.size());
         span.triBase = static_cast<int64_t>(triId.size());
+        span.triCount = mesh.triangle_count;
         span.extent = extent;
         for (int k = 0; k < 3; ++k)
         {
@@ -401,6 +413,73 @@ void buildScene(rt_tracer* t, const rt_scene* scene)
         spans.push_back(span);
     }
 
+    // ---- the scene cache of the trace kernel: what goes into LDS behind the traversal stacks ----
+    // The top of every mesh's tree (a prefix of its breadth-first node order; all of it when it
+    // fits) and then, smallest mesh first, the triangles of the meshes that still fit, as 80-byte
+    // records (nine vertex coordinates and the rank / admission word; the reference box, read only
+    // for hits near an edge, stays in global memory).  RT_AMD_LDS_CACHE=0 leaves the cache empty.
+    require(maxDepth <= 48, "mesh tree too deep for the traversal stack");
+    std::vector<unsigned char> cacheImage;
+    {
+        size_t budget = rtd::traceCacheBudget(std::max(1, maxDepth));
+        if (const char* v = std::getenv("RT_AMD_LDS_CACHE"))
+        {
+            if (std::atoi(v) == 0) budget = 0;
+        }
+        size_t wanted = 0, smallNodes = 0, largeNodes = 0;
+        for (const MeshSpan& span : spans)
+        {
+            wanted += 64 * static_cast<size_t>(span.nodeCount);
+            (span.nodeCount <= 32 ? smallNodes : largeNodes) += static_cast<size_t>(span.nodeCount);
+        }
+        const size_t nodeBudget = budget / 64;
+        const size_t forLarge = nodeBudget > smallNodes ? nodeBudget - smallNodes : 0;
+        for (MeshSpan& span : spans)
+        {
+            size_t share = static_cast<size_t>(span.nodeCount);
+            if (wanted > budget)
+            {
+                if (span.nodeCount <= 32)
+                {
+                    share = nodeBudget >= smallNodes ? share : 0;
+                }
+                else
+                {
+                    share = std::min(share, forLarge * static_cast<size_t>(span.nodeCount) / std::max<size_t>(1, largeNodes));
+                }
+            }
+            span.ldsNodeCount = static_cast<int32_t>(share);
+            span.ldsNodeOffset = static_cast<int32_t>(cacheImage.size());
+            const unsigned char* first = reinterpret_cast<const unsigned char*>(nodes.data() + span.nodeBase);
+            cacheImage.insert(cacheImage.end(), first, first + 64 * share);
+        }
+        std::vector<size_t> bySize(spans.size());
+        for (size_t i = 0; i < spans.size(); ++i) bySize[i] = i;
+        std::sort(bySize.begin(), bySize.end(), [&](size_t a, size_t b) { return spans[a].triCount < spans[b].triCount; });
+        for (size_t i : bySize)
+        {
+            MeshSpan& span = spans[i];
+            const size_t bytes = 80 * static_cast<size_t>(span.triCount);
+            if (span.triCount == 0 || cacheImage.size() + bytes > budget) continue;
+            span.ldsTriOffset = static_cast<int32_t>(cacheImage.size());
+            for (int64_t slot = 0; slot < span.triCount; ++slot)
+            {
+                const unsigned char* record = reinterpret_cast<const unsigned char*>(triRec.data() + 16 * (span.triBase + slot));
+                cacheImage.insert(cacheImage.end(), record, record + 80);
+            }
+        }
+        cacheImage.resize((cacheImage.size() + 15) & ~static_cast<size_t>(15), 0);
+        if (std::getenv("RT_AMD_VERBOSE"))
+        {
+            std::fprintf(stderr, "[rt_amd] scene cache: %zu of %zu bytes of LDS\n", cacheImage.size(), budget);
+            for (size_t i = 0; i < spans.size(); ++i)
+            {
+                std::fprintf(stderr, "[rt_amd]   mesh %zu: %d of %d nodes, triangles %s\n", i, spans[i].ldsNodeCount,
+                             spans[i].nodeCount, spans[i].ldsTriOffset >= 0 ? "cached" : "in global memory");
+            }
+        }
+    }
+
     // ---- volumes ----
     std::vector<rtd::Volume> volumes;
     for (int64_t i = 0; i < scene->volume_count; ++i)
@@ -410,6 +489,7 @@ void buildScene(rt_tracer* t, const rt_scene* scene)
         rtd::Volume v{};
         v.type = rv.type;
         v.material = rv.material;
+        v.ldsTriOffset = -1;
         std::memcpy(v.pos, rv.position, sizeof(v.pos));
         v.rot = rtd::Quat{rv.rotation[0], rv.rotation[1], rv.rotation[2], rv.rotation[3]};
         v.inv = quatInverse(v.rot);
@@ -423,11 +503,29 @@ void buildScene(rt_tracer* t, const rt_scene* scene)
             v.nodeCount = spans[rv.mesh].nodeCount;
             v.triBase = spans[rv.mesh].triBase;
             v.extent = spans[rv.mesh].extent;
+            v.ldsNodeCount = spans[rv.mesh].ldsNodeCount;
+            v.ldsNodeOffset = spans[rv.mesh].ldsNodeOffset;
+            v.ldsTriOffset = spans[rv.mesh].ldsTriOffset;
         }
         else
         {
             require(rv.type == RT_VOLUME_SPHERE || rv.type == RT_VOLUME_QUAD || rv.type == RT_VOLUME_PLANE,
                     "unknown volume type");
+        }
+        // pose number: the first static volume with the same position and rotation bits
+        v.poseId = static_cast<int32_t>(i);
+        if (v.animation < 0)
+        {
+            for (int64_t j = 0; j < i; ++j)
+            {
+                if (volumes[static_cast<size_t>(j)].animation < 0 &&
+                    std::memcmp(scene->volumes[j].position, rv.position, sizeof(rv.position)) == 0 &&
+                    std::memcmp(scene->volumes[j].rotation, rv.rotation, sizeof(rv.rotation)) == 0)
+                {
+                    v.poseId = volumes[static_cast<size_t>(j)].poseId;
+                    break;
+                }
+            }
         }
         // world-space box of a static volume: its object-space corners through the volume's
         // transform, grown by a millionth of the scene's scale (the transforms round at 1e-16 of it)
@@ -653,6 +751,7 @@ void buildScene(rt_tracer* t, const rt_scene* scene)
     t->keyframes.upload(keyframes);
 
     t->volumes.upload(volumes);
+    t->cacheImage.upload(cacheImage);
     t->nodes.upload(nodes);
     t->triRec.upload(triRec);
     t->triNrm.upload(triNrm);
@@ -684,8 +783,9 @@ void buildScene(rt_tracer* t, const rt_scene* scene)
     view.windowStart = windowStart;
     view.windowEnd = windowEnd;
     view.hasCamera = scene->camera_count > 0 ? 1 : 0;
-    require(maxDepth <= 48, "mesh tree too deep for the traversal stack");
     view.stackDepth = std::max(1, maxDepth);
+    view.cacheBytes = static_cast<uint32_t>(cacheImage.size());
+    view.cacheImage = t->cacheImage.ptr;
     view.patches = t->patches.ptr;
     view.patchCount = static_cast<int32_t>(patches.size());
     view.frameTime = start;
@@ -1101,10 +1201,20 @@ int32_t rt_check_tree(const double* tri_pos, int64_t count, int32_t leaf_size, d
         // references from the root reaches every leaf's slots exactly once
         const rtbvh::WideMesh wide = rtbvh::widen(tree);
         require(!wide.nodes.empty(), "walk has no root");
+        // the device walks the breadth-first numbering: same nodes, every child behind its parent
+        const rtbvh::WideMesh walked = rtbvh::breadthFirst(wide);
+        require(walked.nodes.size() == wide.nodes.size(), "breadth-first numbering lost or repeated a node");
+        for (size_t i = 0; i < walked.nodes.size(); ++i)
+        {
+            for (int32_t child : {walked.nodes[i].left, walked.nodes[i].right})
+            {
+                require(child < 0 || static_cast<size_t>(child) > i, "breadth-first numbering puts a child before its parent");
+            }
+        }
         {
             std::vector<char> slotSeen(n, 0);
             std::vector<std::pair<int32_t, int>> pending{{0, 1}};  // (reference, inner levels so far)
-            std::vector<char> nodeSeen(wide.nodes.size(), 0);
+            std::vector<char> nodeSeen(walked.nodes.size(), 0);
             int deepest = 0;
             while (!pending.empty())
             {
@@ -1124,11 +1234,11 @@ int32_t rt_check_tree(const double* tri_pos, int64_t count, int32_t leaf_size, d
                     }
                     continue;
                 }
-                require(static_cast<size_t>(ref) < wide.nodes.size() && !nodeSeen[static_cast<size_t>(ref)],
+                require(static_cast<size_t>(ref) < walked.nodes.size() && !nodeSeen[static_cast<size_t>(ref)],
                         "node reference out of range or repeated");
                 nodeSeen[static_cast<size_t>(ref)] = 1;
                 deepest = std::max(deepest, level);
-                const rtbvh::WideNode& node = wide.nodes[static_cast<size_t>(ref)];
+                const rtbvh::WideNode& node = walked.nodes[static_cast<size_t>(ref)];
                 pending.push_back({node.left, level + 1});
                 pending.push_back({node.right, level + 1});
             }
@@ -1550,15 +1660,25 @@ rtd::TraceArgs passArguments(const rt_tracer* tracer, const rt_trace_params* par
 // as long so that the waves end together.  Returns the number of blocks to launch.
 int scheduleLaunch(rtd::TraceArgs& launch, uint64_t work, int residentBlocks, bool ordered)
 {
-    const uint64_t waves = static_cast<uint64_t>(residentBlocks) * 4;
+    const uint64_t wavesPerBlock = static_cast<uint64_t>(rtd::traceBlockThreads()) / 64;
+    const uint64_t waves = static_cast<uint64_t>(residentBlocks) * wavesPerBlock;
     uint64_t chunk = work / (waves * 4);
     // parked photons are in no particular order: short runs, for balance
     chunk = std::min<uint64_t>(ordered ? 4096 : 256, std::max<uint64_t>(64, chunk)) & ~63ull;
     launch.chunk = static_cast<uint32_t>(chunk);
     launch.tailChunk = static_cast<uint32_t>(std::max<uint64_t>(64, (chunk / 4) & ~63ull));
     launch.fullClaims = (work - work / 16) / chunk;
+    // emission-ordered ids: the runs go out in a scattered order (stride ~ 0.618 of their number, coprime to it)
+    launch.claimStride = 1;
+    if (ordered && launch.fullClaims > 2)
+    {
+        uint64_t stride = std::max<uint64_t>(2, static_cast<uint64_t>(0.6180339887 * static_cast<double>(launch.fullClaims)));
+        while (std::gcd(stride, launch.fullClaims) != 1) ++stride;
+        launch.claimStride = stride % launch.fullClaims;
+    }
     const uint64_t wavesNeeded = (work + 63) / 64;
-    return std::max(1, static_cast<int>(std::min<uint64_t>(static_cast<uint64_t>(residentBlocks), (wavesNeeded + 3) / 4)));
+    return std::max(1, static_cast<int>(std::min<uint64_t>(static_cast<uint64_t>(residentBlocks),
+                                                          (wavesNeeded + wavesPerBlock - 1) / wavesPerBlock)));
 }
 
 }  // namespace
@@ -1669,6 +1789,7 @@ int32_t rt_trace(rt_tracer* tracer, const rt_trace_params* params)
             tracer->queueCounts.zero(tracer->stream);
         }
         uint64_t parked = 0;  // photons in the queue the next launch reads
+        const bool verbose = std::getenv("RT_AMD_VERBOSE") != nullptr;
         for (int level = 0; level <= levels; ++level)
         {
             rtd::TraceArgs launch = args;
@@ -1690,8 +1811,8 @@ int32_t rt_trace(rt_tracer* tracer, const rt_trace_params* params)
                 launch.queueOutCapacity = capacity;
             }
             const int blocks = scheduleLaunch(launch, work, residentBlocks, level == 0);
-            rtd::launchTrace(launch, blocks, 256, tracer->stream);
-            check(hipGetLastError(), "trace launch");
+            const auto levelStart = std::chrono::steady_clock::now();
+            check(rtd::launchTrace(launch, blocks, tracer->stream), "trace launch");
             if (level == levels)
             {
                 break;
@@ -1700,6 +1821,12 @@ int32_t rt_trace(rt_tracer* tracer, const rt_trace_params* params)
             check(hipMemcpyAsync(&claimed, counts + 2 * level, sizeof(claimed), hipMemcpyDeviceToHost, tracer->stream),
                   "hipMemcpyAsync queue count");
             check(hipStreamSynchronize(tracer->stream), "hipStreamSynchronize");
+            if (verbose)
+            {
+                const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - levelStart).count();
+                std::fprintf(stderr, "[rt_amd] bounce level %d: %llu photons in, %llu go on, %.3f ms\n", level,
+                             static_cast<unsigned long long>(work), claimed, ms);
+            }
             parked = std::min<uint64_t>(claimed, capacity);
             if (parked == 0)
             {
@@ -1762,8 +1889,7 @@ int32_t rt_trace_static(rt_tracer* tracer, const rt_trace_params* params)
         args.emissionOrder = idsOut;
         const int residentBlocks = tracer->computeUnits * rtd::traceBlocksPerCu(args);
         const int blocks = scheduleLaunch(args, args.totalWork, residentBlocks, true);
-        rtd::launchTrace(args, blocks, 256, tracer->stream);
-        check(hipGetLastError(), "trace launch");
+        check(rtd::launchTrace(args, blocks, tracer->stream), "trace launch");
     });
 }
 
@@ -2019,45 +2145,52 @@ int32_t rt_gather(rt_tracer* tracer, int32_t camera, double gather_cell_size, do
         require(n < (1ull << 31), "bounce store too large for the gather index");
         const double cellSize = gather_cell_size > 0.0 ? gather_cell_size : 1.0;  // reference src/BounceStore.cpp:44
 
-        // index: key every record by its cell, sort (key, record) pairs
-        DeviceArray<unsigned long long> keysIn, keysOut, stats, counts;
-        DeviceArray<uint32_t> orderIn, orderOut;
-        DeviceArray<unsigned char> scratch;
-        DeviceArray<float> sortedStore;
+        // index: key every record by its cell, sort (key, record) pairs.  The work space is kept
+        // between calls (it only grows): a frame gathers once per camera, a sequence once per frame.
+        rt_tracer::GatherSpace& g = tracer->gatherSpace;
+        auto& keysIn = g.keysIn;
+        auto& keysOut = g.keysOut;
+        auto& orderIn = g.orderIn;
+        auto& orderOut = g.orderOut;
+        auto& scratch = g.scratch;
+        auto& sortedStore = g.sortedStore;
+        auto& stats = g.stats;
+        if (stats.count == 0) stats.allocate(4);  // [0..1] the launch's tallies, [2] records that carry a key
         uint64_t indexed = 0;
         if (n > 0)
         {
-            keysIn.allocate(n);
-            keysOut.allocate(n);
-            orderIn.allocate(n);
-            orderOut.allocate(n);
+            if (keysIn.count < n)
+            {
+                keysIn.allocate(n);
+                keysOut.allocate(n);
+                orderIn.allocate(n);
+                orderOut.allocate(n);
+            }
             rtd::launchStoreKeys(tracer->storeRecords.ptr, n, 1.0 / cellSize, keysIn.ptr, orderIn.ptr, tracer->stream);
             check(hipGetLastError(), "store keys launch");
             size_t bytes = 0;
             check(rtd::sortStoreKeys(nullptr, &bytes, keysIn.ptr, keysOut.ptr, orderIn.ptr, orderOut.ptr, n, tracer->stream),
                   "sort size query");
-            scratch.allocate(bytes > 0 ? bytes : 1);
+            if (scratch.count < bytes) scratch.allocate(bytes > 0 ? bytes : 1);
             check(rtd::sortStoreKeys(scratch.ptr, &bytes, keysIn.ptr, keysOut.ptr, orderIn.ptr, orderOut.ptr, n,
                                      tracer->stream),
                   "store sort");
             check(hipGetLastError(), "store sort");
             // records whose cell could not be packed sort to the end; find where they start
-            counts.allocate(1);
-            rtd::launchCountIndexed(keysOut.ptr, n, counts.ptr, tracer->stream);
+            rtd::launchCountIndexed(keysOut.ptr, n, stats.ptr + 2, tracer->stream);
             unsigned long long hostIndexed = 0;
-            check(hipMemcpyAsync(&hostIndexed, counts.ptr, sizeof(hostIndexed), hipMemcpyDeviceToHost, tracer->stream),
+            check(hipMemcpyAsync(&hostIndexed, stats.ptr + 2, sizeof(hostIndexed), hipMemcpyDeviceToHost, tracer->stream),
                   "hipMemcpyAsync indexed");
             check(hipStreamSynchronize(tracer->stream), "hipStreamSynchronize");
             indexed = hostIndexed;
             if (indexed > 0)
             {
-                sortedStore.allocate(13 * indexed);
+                if (sortedStore.count < 13 * indexed) sortedStore.allocate(13 * n);
                 rtd::launchReorderStore(tracer->storeRecords.ptr, orderOut.ptr, indexed, sortedStore.ptr, tracer->stream);
                 check(hipGetLastError(), "store reorder launch");
             }
         }
-        stats.allocate(2);
-        stats.zero(tracer->stream);
+        check(hipMemsetAsync(stats.ptr, 0, 2 * sizeof(unsigned long long), tracer->stream), "hipMemsetAsync gather stats");
 
         rtd::GatherArgs args{};
         args.scene = tracer->view;
@@ -2075,7 +2208,13 @@ int32_t rt_gather(rt_tracer* tracer, int32_t camera, double gather_cell_size, do
         args.stats = stats.ptr;
         if (cache.total > 0)
         {
-            rtd::launchGather(args, tracer->stream);
+            // Lanes per sampled pixel, by how many records a gather point meets on average: a few
+            // camera pixels over a densely lit surface get a wave each, a 4K frame over a thin store
+            // keeps one lane per pixel.  (RT_AMD_GATHER_LANES=1|8|64 overrides, for measurements.)
+            const uint64_t perPoint = indexed / std::max<uint64_t>(1, cache.total);
+            int lanes = perPoint >= 64 ? 64 : (perPoint >= 3 ? 8 : 1);
+            if (const char* v = std::getenv("RT_AMD_GATHER_LANES")) lanes = std::atoi(v);
+            rtd::launchGather(args, lanes, tracer->stream);
             check(hipGetLastError(), "gather launch");
         }
         unsigned long long hostStats[2] = {0, 0};

@@ -431,6 +431,41 @@ WideMesh widen(const FlatMesh& tree)
     return out;
 }
 
+WideMesh breadthFirst(const WideMesh& mesh)
+{
+    WideMesh out;
+    out.pushDepth = mesh.pushDepth;
+    const size_t count = mesh.nodes.size();
+    std::vector<int32_t> newIndex(count, -1), order;
+    order.reserve(count);
+    if (count > 0)
+    {
+        newIndex[0] = 0;
+        order.push_back(0);
+    }
+    for (size_t head = 0; head < order.size(); ++head)
+    {
+        const WideNode& node = mesh.nodes[static_cast<size_t>(order[head])];
+        for (int32_t child : {node.left, node.right})
+        {
+            if (child >= 0 && newIndex[static_cast<size_t>(child)] < 0)
+            {
+                newIndex[static_cast<size_t>(child)] = static_cast<int32_t>(order.size());
+                order.push_back(child);
+            }
+        }
+    }
+    out.nodes.reserve(order.size());
+    for (int32_t old : order)
+    {
+        WideNode node = mesh.nodes[static_cast<size_t>(old)];
+        if (node.left >= 0) node.left = newIndex[static_cast<size_t>(node.left)];
+        if (node.right >= 0) node.right = newIndex[static_cast<size_t>(node.right)];
+        out.nodes.push_back(node);
+    }
+    return out;
+}
+
 FlatMesh build(const double* tri_pos, int64_t count)
 {
     Builder b;

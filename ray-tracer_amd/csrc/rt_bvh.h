@@ -77,4 +77,9 @@ struct WideMesh
 
 WideMesh widen(const FlatMesh& tree);
 
+// The same nodes numbered breadth-first from the root (widen() numbers them in preorder): the
+// first k nodes are then the top of the tree, the part every ray walks through, which a kernel
+// can keep in LDS as one contiguous block.
+WideMesh breadthFirst(const WideMesh& mesh);
+
 }  // namespace rtbvh

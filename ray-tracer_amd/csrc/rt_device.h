@@ -168,6 +168,13 @@ struct Volume
     // the cast skips it without transforming the ray.
     float worldBox[6];
     double extent;           // largest |coordinate| of the mesh (scale of the pruning slack)
+    // What the trace kernel keeps of this mesh in LDS (SceneView::cacheImage): its first
+    // ldsNodeCount nodes (breadth-first numbering: the top of the tree) at byte ldsNodeOffset of the
+    // image, and, when ldsTriOffset >= 0, all its triangles as 80-byte records (vertices + word).
+    int32_t ldsNodeCount, ldsNodeOffset, ldsTriOffset;
+    // Volumes with the same number share position and rotation bit for bit (and are not keyframed):
+    // a ray taken into the object space of one of them is in the object space of all of them.
+    int32_t poseId;
     double pos[3];
     Quat rot, inv;    // rotation and Quaternion::inverse() of it (src/Quaternion.cpp:49-52)
     double param[18];
@@ -257,6 +264,11 @@ struct SceneView
     const rt_animation* animations;
     const rt_keyframe* keyframes;
     int32_t animationCount;
+    // The part of the scene the trace kernel copies into LDS behind its traversal stacks: the top of
+    // every mesh's tree and the triangles of the meshes that fit (Volume::lds*).  cacheBytes is a
+    // multiple of 16; 0 = nothing is cached.
+    uint32_t cacheBytes;
+    const unsigned char* cacheImage;
 };
 
 struct Ray
@@ -589,6 +601,25 @@ RT_DEV TraversalStack laneStack()
     return TraversalStack{rtTraversalStack + threadIdx.x, static_cast<int32_t>(blockDim.x)};
 }
 
+// The scene cache of the trace kernel lies behind the block's stacks.
+RT_DEV unsigned char* sceneCache(const SceneView& s)
+{
+    extern __shared__ unsigned long long rtTraversalStack[];
+    return reinterpret_cast<unsigned char*>(rtTraversalStack + static_cast<uint32_t>(s.stackDepth) * blockDim.x);
+}
+
+// Copies SceneView::cacheImage into LDS (every thread of the block takes part; ends with a barrier).
+RT_DEV void fillSceneCache(const SceneView& s)
+{
+    uint4* dst = reinterpret_cast<uint4*>(sceneCache(s));
+    const uint4* src = reinterpret_cast<const uint4*>(s.cacheImage);
+    for (uint32_t i = threadIdx.x; i < s.cacheBytes / 16; i += blockDim.x)
+    {
+        dst[i] = src[i];
+    }
+    __syncthreads();
+}
+
 // Slab test of one child box of a node, in single precision with packed operations.  The
 // boxes are grown (on the host) by far more than single precision loses on coordinates of the
 // scene's size, so that every parameter interval computed here CONTAINS the true one: a box
@@ -657,9 +688,13 @@ RT_DEV bool slabTestChild(const RayPrepSingle& q, const float* box, float* entry
 // without another fetch.  Triangle tests are deferred until every lane of the wave has
 // either reached a leaf or run out of nodes, so that the lanes test triangles together
 // instead of one lane at a time.
+// Cached: the kernel holds the top of the tree (ldsNodeCount nodes at ldsNodes) and possibly the
+// mesh's triangles (ldsTris, 10 doubles each; null: none) in LDS.
+template <bool Cached>
 RT_DEV bool castMesh(const SceneView& s, int32_t nodeBase, int32_t nodeCount, int64_t triBase, double extent,
                      const Ray& ray, const RayPrep& prep, const TraversalStack& stack, double bound, double* bary,
-                     Vec* position, double* distance, int32_t* triSlot)
+                     Vec* position, double* distance, int32_t* triSlot, int32_t ldsNodeCount = 0,
+                     const unsigned char* ldsNodes = nullptr, const double* ldsTris = nullptr)
 {
     if (nodeCount <= 0)
     {
@@ -696,7 +731,11 @@ RT_DEV bool castMesh(const SceneView& s, int32_t nodeBase, int32_t nodeCount, in
                 float leftBox[6], rightBox[6];
                 int32_t left, right;
                 const int32_t shared = __builtin_amdgcn_readfirstlane(cur);
+#ifdef RT_EXPERIMENT_LDS_UNIFORM
+                if (__ballot(cur != shared) == 0 && !(Cached && shared < ldsNodeCount))
+#else
                 if (__ballot(cur != shared) == 0)
+#endif
                 {
                     const auto node = uniformRead(nodes + shared);
 #pragma unroll
@@ -710,11 +749,24 @@ RT_DEV bool castMesh(const SceneView& s, int32_t nodeBase, int32_t nodeCount, in
                 }
                 else
                 {
-                    const Node& node = nodes[cur];
-                    const float4 q0 = reinterpret_cast<const float4*>(&node)[0];
-                    const float4 q1 = reinterpret_cast<const float4*>(&node)[1];
-                    const float4 q2 = reinterpret_cast<const float4*>(&node)[2];
-                    const int4 links = reinterpret_cast<const int4*>(&node)[3];
+                    float4 q0, q1, q2;
+                    int4 links;
+                    if (Cached && cur < ldsNodeCount)
+                    {
+                        const float4* node = reinterpret_cast<const float4*>(ldsNodes + 64u * static_cast<uint32_t>(cur));
+                        q0 = node[0];
+                        q1 = node[1];
+                        q2 = node[2];
+                        links = reinterpret_cast<const int4*>(node)[3];
+                    }
+                    else
+                    {
+                        const Node& node = nodes[cur];
+                        q0 = reinterpret_cast<const float4*>(&node)[0];
+                        q1 = reinterpret_cast<const float4*>(&node)[1];
+                        q2 = reinterpret_cast<const float4*>(&node)[2];
+                        links = reinterpret_cast<const int4*>(&node)[3];
+                    }
                     leftBox[0] = q0.x; leftBox[1] = q0.y; leftBox[2] = q0.z; leftBox[3] = q0.w; leftBox[4] = q1.x; leftBox[5] = q1.y;
                     rightBox[0] = q1.z; rightBox[1] = q1.w; rightBox[2] = q2.x; rightBox[3] = q2.y; rightBox[4] = q2.z; rightBox[5] = q2.w;
                     left = links.x;
@@ -775,8 +827,20 @@ RT_DEV bool castMesh(const SceneView& s, int32_t nodeBase, int32_t nodeCount, in
             Vec pos;
             const double* rec = triRec + 16 * t;
             // rank and admission weight travel with the vertices: same 128-byte line, same wait
-            const unsigned long long word = reinterpret_cast<const unsigned long long*>(rec)[9];
-            if (rayIntersectsTriangle(ray, prep, rec, b3, &pos, &d))
+            unsigned long long word;
+            bool hitsTriangle;
+            if (Cached && ldsTris != nullptr)
+            {
+                const double* cached = ldsTris + 10 * t;
+                word = reinterpret_cast<const unsigned long long*>(cached)[9];
+                hitsTriangle = rayIntersectsTriangle(ray, prep, cached, b3, &pos, &d);
+            }
+            else
+            {
+                word = reinterpret_cast<const unsigned long long*>(rec)[9];
+                hitsTriangle = rayIntersectsTriangle(ray, prep, rec, b3, &pos, &d);
+            }
+            if (hitsTriangle)
             {
                 const int32_t rank = static_cast<int32_t>(static_cast<uint32_t>(word));
                 bool wins = !found || d < best || (d == best && rank < bestRank);
@@ -937,7 +1001,7 @@ RT_DEV Quat quatInverse(const Quat& q)  // reference src/Quaternion.cpp:39-52
 // produced (occlusion test, src/Worker.cpp:314-333).  With Animated set, a keyframed
 // volume is posed at `time` (the photon's or the camera sample's) for the cast; without
 // it every volume keeps its scene-load transform and `time` is unused.
-template <bool Animated>
+template <bool Animated, bool Cached = false>
 RT_DEV bool castScene(const SceneView& s, const Ray& ray, float time, double selfHit, bool needSurface, Hit* out)
 {
     const TraversalStack stack = laneStack();
@@ -955,6 +1019,11 @@ RT_DEV bool castScene(const SceneView& s, const Ray& ray, float time, double sel
         worldOod[i] = dabs(d) < kEps ? __builtin_inf() : 1.0 / d;
     }
     const double worldLength = magnitude(ray.d);
+    Ray local;
+    local.o = local.d = mk(0, 0, 0);
+    RayPrep prep = {};
+    int32_t heldPose = -1;  // Volume::poseId of the pose `local` is in (none yet)
+    bool prepared = false;  // `prep` belongs to `local`
     for (int32_t v = 0; v < s.volumeCount; ++v)
     {
         const auto vol = uniformRead(s.volumes + v);  // v is the same in every lane
@@ -977,29 +1046,50 @@ RT_DEV bool castScene(const SceneView& s, const Ray& ray, float time, double sel
                 continue;
             }
         }
-        Vec vpos = mk(vol->pos[0], vol->pos[1], vol->pos[2]);
-        Quat inv = Quat{vol->inv.x, vol->inv.y, vol->inv.z, vol->inv.w};
-        if (Animated && vol->animation >= 0)
+        // the ray in the volume's object space, and what the mesh tests derive from it: kept while
+        // the volumes that follow share the pose (the walls of a room are one pose)
+        if (vol->poseId != heldPose)
         {
-            const Pose pose = poseAt(s, vol->animation, time);
-            vpos = pose.position;
-            inv = quatInverse(pose.rotation);
+            Vec vpos = mk(vol->pos[0], vol->pos[1], vol->pos[2]);
+            Quat inv = Quat{vol->inv.x, vol->inv.y, vol->inv.z, vol->inv.w};
+            if (Animated && vol->animation >= 0)
+            {
+                const Pose pose = poseAt(s, vol->animation, time);
+                vpos = pose.position;
+                inv = quatInverse(pose.rotation);
+            }
+            local.o = rotate(inv, ray.o - vpos);
+            local.d = rotate(inv, ray.d);
+            heldPose = vol->poseId;
+            prepared = false;
         }
-        Ray local;
-        local.o = rotate(inv, ray.o - vpos);
-        local.d = rotate(inv, ray.d);
         Vec pos, nrm = mk(0, 0, 0);
         double dist;
         bool found = false;
         int32_t tri = -1;
         if (type == RT_VOLUME_MESH)
         {
-            const RayPrep prep = prepareRay(local);
+            if (!prepared)
+            {
+                prep = prepareRay(local);
+                prepared = true;
+            }
             double bary[3];
             int32_t slot = 0;
             const int64_t triBase = vol->triBase;
-            found = castMesh(s, vol->nodeBase, vol->nodeCount, triBase, vol->extent, local, prep, stack, minDistance, bary,
-                             &pos, &dist, &slot);
+            if (Cached)
+            {
+                const unsigned char* cache = sceneCache(s);
+                const int32_t triOffset = vol->ldsTriOffset;
+                found = castMesh<true>(s, vol->nodeBase, vol->nodeCount, triBase, vol->extent, local, prep, stack, minDistance,
+                                       bary, &pos, &dist, &slot, vol->ldsNodeCount, cache + vol->ldsNodeOffset,
+                                       triOffset >= 0 ? reinterpret_cast<const double*>(cache + triOffset) : nullptr);
+            }
+            else
+            {
+                found = castMesh<false>(s, vol->nodeBase, vol->nodeCount, triBase, vol->extent, local, prep, stack, minDistance,
+                                        bary, &pos, &dist, &slot);
+            }
             if (found && dist < minDistance && dist > selfHit)
             {
                 if (needSurface)

@@ -111,6 +111,7 @@ struct TraceArgs
     uint32_t chunk;                 // photon ids a wave claims at a time (<= 4096, multiple of 64) ...
     uint32_t tailChunk;             // ... for the first `fullClaims` claims of the launch, then this many: the
     uint64_t fullClaims;            // end of a launch is handed out in small pieces so that the waves end together
+    uint64_t claimStride;           // full claim c takes run (c * claimStride) % fullClaims of the list (1: in list order)
     const uint32_t* emissionOrder;  // optional: position in the pass -> photon id, sorted by emission cell
     uint64_t firstPhoton;
     uint64_t photonCount;  // per light
@@ -125,7 +126,9 @@ struct TraceArgs
     uint64_t queueOutCapacity;                // beyond it a photon is followed on in its lane
 };
 
-void launchTrace(const TraceArgs& args, int blocks, int threads, hipStream_t stream);
+hipError_t launchTrace(const TraceArgs& args, int blocks, hipStream_t stream);
+int traceBlockThreads();                   // threads of a trace block (one block per CU)
+size_t traceCacheBudget(int stackDepth);   // LDS bytes a trace block has for the scene cache behind its stacks
 // Whole-pass emission order: keys and ids of every photon of the pass, then a radix sort of the pairs.
 // The sorts and the scan below follow hipCUB's convention: with a null `scratch` nothing runs and
 // *scratchBytes receives the work space the call needs; the library's status is returned.
@@ -178,7 +181,8 @@ void launchCountIndexed(const unsigned long long* sortedKeys, uint64_t n, unsign
 // sorted[j] = store[order[j]] for the first `indexed` positions: the gather then reads a cell's
 // records from consecutive rows instead of chasing the sort's permutation record by record.
 void launchReorderStore(const float* store, const uint32_t* order, uint64_t indexed, float* sorted, hipStream_t stream);
-void launchGather(const GatherArgs& args, hipStream_t stream);
+// lanesPerPixel: 1, 8 or 64 lanes work on one sampled pixel's records (same additions in the same order)
+void launchGather(const GatherArgs& args, int lanesPerPixel, hipStream_t stream);
 // Device-side build of the probe grid (rt_set_probes): see the kernels in rt_kernels.hip.
 struct ProbeBuild
 {

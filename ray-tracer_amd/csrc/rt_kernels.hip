@@ -325,8 +325,37 @@ RT_DEV void storeAppend(const StoreView& sv, bool keep, const Vec& position, con
     }
 }
 
+// Tallies of one launch.  They live in LDS, not in registers (the trace kernels have none to
+// spare): one set of event counters per WAVE — an event is counted for all the lanes it happens in
+// at once, by a ballot and one addition of the lowest such lane — and the deposited power per
+// lane.  Each wave adds its set to the pass counters when it ends.
+enum TallySlot
+{
+    kTallyPhotons = 0, kTallyCasts, kTallyBounces, kTallyDeposits, kTallyKept, kTallyCulled,
+    kTallySplatTotal, kTallySplatRadiusClamped, kTallySplatLuminanceClamped,
+    kTallyDensityCells, kTallyDensityDeposits, kTallyDensityOverflow, kTallySlots
+};
+
+struct WaveTally
+{
+    unsigned int* slots;  // [kTallySlots] of this wave
+    double* power;        // this lane's three sums, kTraceThreads apart
+};
+
+// Counts the lanes that execute this call with `happened` set.
+RT_DEV void tally(const WaveTally& t, int slot, bool happened = true)
+{
+    const unsigned long long mask = __ballot(happened);
+    if (happened && static_cast<int>(threadIdx.x & 63) == __builtin_ctzll(mask))
+    {
+        // different lanes of the wave add at different times: an LDS atomic, so that no lane works on a remembered value
+        __hip_atomic_fetch_add(t.slots + slot, static_cast<unsigned int>(__builtin_popcountll(mask)), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+}
+
 // DensityGrid::add, reference src/DensityGrid.cpp:25-34.
-RT_DEV void densityAdd(const DensityView& dv, const Vec& p, const Color& power, uint32_t& newCells, uint32_t& overflow)
+RT_DEV void densityAdd(const DensityView& dv, const Vec& p, const Color& power, const WaveTally& lc)
 {
     const int64_t cx = static_cast<int64_t>(__builtin_floor(p.x * dv.invCellSize));
     const int64_t cy = static_cast<int64_t>(__builtin_floor(p.y * dv.invCellSize));
@@ -334,7 +363,7 @@ RT_DEV void densityAdd(const DensityView& dv, const Vec& p, const Color& power, 
     const int64_t lim = 1 << 20;
     if (cx < -lim || cx >= lim || cy < -lim || cy >= lim || cz < -lim || cz >= lim)
     {
-        overflow += 1;
+        tally(lc, kTallyDensityOverflow);
         return;
     }
     const unsigned long long key = (static_cast<unsigned long long>(cx + lim) << 42) |
@@ -352,10 +381,7 @@ RT_DEV void densityAdd(const DensityView& dv, const Vec& p, const Color& power, 
         const unsigned long long seen = atomicCAS(dv.keys + slot, kEmptyKey, key);
         if (seen == kEmptyKey || seen == key)
         {
-            if (seen == kEmptyKey)
-            {
-                newCells += 1;
-            }
+            tally(lc, kTallyDensityCells, seen == kEmptyKey);
             atomicAdd(dv.power + 3 * slot + 0, power.r);
             atomicAdd(dv.power + 3 * slot + 1, power.g);
             atomicAdd(dv.power + 3 * slot + 2, power.b);
@@ -364,25 +390,15 @@ RT_DEV void densityAdd(const DensityView& dv, const Vec& p, const Color& power, 
         }
         slot = (slot + 1) & dv.slotMask;
     }
-    overflow += 1;
+    tally(lc, kTallyDensityOverflow);
 }
-
-// Per-lane tallies of one launch, summed per wave at its end.  32 bits each: a lane sees
-// (photons of the launch / lanes of the grid) x bounces events, far below 2^32.
-struct LocalCounters
-{
-    uint32_t photons = 0, casts = 0, bounces = 0, deposits = 0, kept = 0, culled = 0;
-    uint32_t splatTotal = 0, splatRadiusClamped = 0, splatLuminanceClamped = 0;
-    uint32_t densityCells = 0, densityDeposits = 0, densityOverflow = 0;
-    double power[3] = {0.0, 0.0, 0.0};
-};
 
 // Worker::splatToCamera, reference src/Worker.cpp:221-427, with
 // Camera::coordForPointSubPixel (src/Camera.cpp:239-310), Utility::flooredSplatRadius
 // (src/Utility.cpp:43-50) and Buffer::addColor (src/Buffer.cpp:22-37).
 template <bool Animated>
 RT_DEV void splatToCamera(const TraceArgs& a, const Vec& incoming, const Color& photonColor, int bounces, int lightId,
-                          float time, const Hit& hit, const Material& material, LocalCounters& lc)
+                          float time, const Hit& hit, const Material& material, const WaveTally& lc)
 {
     const SceneView& s = a.scene;
     if (materialIsDelta(material.type) || static_cast<double>(s.photonsPerLight) <= 0.0)
@@ -427,15 +443,15 @@ RT_DEV void splatToCamera(const TraceArgs& a, const Vec& incoming, const Color& 
         shadow.o = hit.position;
         shadow.d = toCameraDir;
         Hit occluder;
-        if (castScene<Animated>(s, shadow, time, kSelfHitThreshold, false, &occluder) && occluder.distance < cameraDistance)
+        if (castScene<Animated, true>(s, shadow, time, kSelfHitThreshold, false, &occluder) && occluder.distance < cameraDistance)
         {
             continue;
         }
 
         const double rawRadius = cameraDistance * cam.tanPixelHalfAngle;
         const double r = (a.minSplatRadius > 0.0 && rawRadius < a.minSplatRadius) ? a.minSplatRadius : rawRadius;
-        lc.splatTotal += 1;
-        if (r > rawRadius) lc.splatRadiusClamped += 1;
+        tally(lc, kTallySplatTotal);
+        tally(lc, kTallySplatRadiusClamped, r > rawRadius);
         if (r <= 0.0) continue;
 
         const Color brdf = evaluateMaterial(material, wi, toCameraDir, hit.normal);
@@ -451,7 +467,7 @@ RT_DEV void splatToCamera(const TraceArgs& a, const Vec& incoming, const Color& 
             if (b > s.splatLuminanceClamp)
             {
                 clamped = contribution * static_cast<float>(s.splatLuminanceClamp / b);
-                lc.splatLuminanceClamped += 1;
+                tally(lc, kTallySplatLuminanceClamped);
             }
         }
         const uint64_t index = ((py * w) + px) * 3;
@@ -494,27 +510,12 @@ RT_DEV unsigned long long photonAt(const TraceArgs& a, unsigned long long positi
     return a.emissionOrder ? static_cast<unsigned long long>(a.emissionOrder[position]) : position;
 }
 
-// The two uniform draws that steer photon `id`'s initial direction.
-RT_DEV void emissionDraws(const TraceArgs& a, unsigned long long id, Rng& rng, double* u0, double* u1)
-{
-    int lightId;
-    unsigned long long photonIndex;
-    splitPhotonId(a, id, &lightId, &photonIndex);
-    rng.begin(static_cast<uint32_t>(lightId), photonIndex, RT_STAGE_EMIT);
-    *u0 = rng.value();
-    *u1 = rng.value();
-    if (a.scene.lights[lightId].type == RT_LIGHT_AREA)
-    {
-        // an area light draws its origin first; the direction comes from draws 3 and 4
-        *u0 = rng.value();
-        *u1 = rng.value();
-    }
-}
-
-// Whole-pass emission order: every id gets the Morton number of its cell in a 4096 x 4096 grid
-// over the two steering draws (above it the light, so that lights do not interleave); a radix
-// sort of (key, id) then puts photons that leave a light in nearly the same direction next to
-// each other across the whole pass.
+// Whole-pass emission order: every id gets a key that puts photons with nearly the same initial ray
+// next to each other, above it the light (so that lights do not interleave); a radix sort of
+// (key, id) then orders the whole pass.  A light that emits from a point is keyed by the Morton
+// number of its cell in a 4096 x 4096 grid over the two draws that steer the direction.  An area
+// light also draws the ray's origin on its face: rays of one direction that start a face apart share
+// nothing, so its key interleaves four draws, 64 cells each: origin (2) and direction (2).
 constexpr int kGlobalAxisBits = 12;
 
 RT_DEV uint32_t spreadBits12(uint32_t v)
@@ -534,15 +535,37 @@ __global__ void emissionKeysKernel(const TraceArgs a, uint32_t* keys, uint32_t* 
     rng.tape = nullptr;
     rng.next = 0;
     rng.seed = a.scene.seed;
-    double u0, u1;
-    emissionDraws(a, id, rng, &u0, &u1);
-    const uint32_t axis = 1u << kGlobalAxisBits;
-    const uint32_t cx = static_cast<uint32_t>(u0 * axis) & (axis - 1);
-    const uint32_t cy = static_cast<uint32_t>(u1 * axis) & (axis - 1);
     int lightId;
     unsigned long long photonIndex;
     splitPhotonId(a, id, &lightId, &photonIndex);
-    keys[id] = (static_cast<uint32_t>(lightId & 0xFF) << (2 * kGlobalAxisBits)) | spreadBits12(cx) | (spreadBits12(cy) << 1);
+    rng.begin(static_cast<uint32_t>(lightId), photonIndex, RT_STAGE_EMIT);
+    const double u0 = rng.value(), u1 = rng.value();
+    uint32_t cell;
+    if (a.scene.lights[lightId].type == RT_LIGHT_AREA)
+    {
+        // draws 1 and 2 place the origin on the face, 3 and 4 steer the direction
+        const double u2 = rng.value(), u3 = rng.value();
+        const double u[4] = {u0, u1, u2, u3};
+        cell = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+        {
+            const uint32_t c = static_cast<uint32_t>(u[k] * 64.0) & 63u;
+#pragma unroll
+            for (int bit = 0; bit < 6; ++bit)
+            {
+                cell |= ((c >> bit) & 1u) << (4 * bit + (3 - k));
+            }
+        }
+    }
+    else
+    {
+        const uint32_t axis = 1u << kGlobalAxisBits;
+        const uint32_t cx = static_cast<uint32_t>(u0 * axis) & (axis - 1);
+        const uint32_t cy = static_cast<uint32_t>(u1 * axis) & (axis - 1);
+        cell = spreadBits12(cx) | (spreadBits12(cy) << 1);
+    }
+    keys[id] = (static_cast<uint32_t>(lightId & 0xFF) << (2 * kGlobalAxisBits)) | cell;
     ids[id] = static_cast<uint32_t>(id);
 }
 
@@ -555,6 +578,7 @@ __global__ __launch_bounds__(kTraceThreads) void traceKernel(const TraceArgs a)
     const int lane = threadIdx.x & 63;
     RT_DIAG_WAVE_BEGIN;
     RT_DIAG_TIC(kernelStart);
+    fillSceneCache(s);
 
     // work of this launch: the pass's emission-ordered id list, or the photons parked by the
     // launch of the previous bounce
@@ -578,7 +602,11 @@ __global__ __launch_bounds__(kTraceThreads) void traceKernel(const TraceArgs a)
     unsigned long long photonIndex = 0;
     long long recordSlot = -1;
     int casts = 0, valid = 0;
-    LocalCounters lc;
+    __shared__ unsigned int tallySlots[kTraceThreads / 64][kTallySlots];
+    __shared__ double tallyPower[3][kTraceThreads];
+    const WaveTally lc{tallySlots[threadIdx.x >> 6], &tallyPower[0][threadIdx.x]};
+    if (lane < kTallySlots) lc.slots[lane] = 0;
+    lc.power[0] = lc.power[kTraceThreads] = lc.power[2 * kTraceThreads] = 0.0;
     Rng rng;
     rng.tape = nullptr;
     rng.next = 0;
@@ -609,7 +637,12 @@ __global__ __launch_bounds__(kTraceThreads) void traceKernel(const TraceArgs a)
                 const unsigned long long claim = __shfl(fresh, 0, 64);
                 const bool full = claim < a.fullClaims;
                 const unsigned long long size = full ? a.chunk : a.tailChunk;
-                chunkBase = full ? claim * a.chunk : a.fullClaims * a.chunk + (claim - a.fullClaims) * a.tailChunk;
+                // Runs of the emission-ordered list are taken in a scattered order: what is in the
+                // store when it overflows is then spread over the whole emission domain, as in the
+                // reference, whose workers meet the photons in index order (a run on its own stays
+                // coherent, which is all a wave needs).
+                const unsigned long long run = a.claimStride > 1 ? (claim * a.claimStride) % a.fullClaims : claim;
+                chunkBase = full ? run * a.chunk : a.fullClaims * a.chunk + (claim - a.fullClaims) * a.tailChunk;
                 chunkNext = 0;
                 chunkCount = chunkBase < totalWork
                                  ? static_cast<uint32_t>(totalWork - chunkBase < size ? totalWork - chunkBase : size)
@@ -704,8 +737,9 @@ __global__ __launch_bounds__(kTraceThreads) void traceKernel(const TraceArgs a)
             if (!done)
             {
                 casts += 1;
+                tally(lc, kTallyCasts);
                 RT_DIAG_TIC(castStart);
-                const bool hitSomething = castScene<Animated>(s, ray, time, kSelfHitThreshold, true, &hit);
+                const bool hitSomething = castScene<Animated, true>(s, ray, time, kSelfHitThreshold, true, &hit);
                 RT_DIAG_TOC(castStart, 1);
                 if (!hitSomething)
                 {
@@ -731,12 +765,13 @@ __global__ __launch_bounds__(kTraceThreads) void traceKernel(const TraceArgs a)
                     p[0] = color.r; p[1] = color.g; p[2] = color.b;
                 }
                 valid += 1;
+                tally(lc, kTallyBounces);
                 if (!delta)
                 {
-                    lc.deposits += 1;
+                    tally(lc, kTallyDeposits);
                     lc.power[0] += color.r;
-                    lc.power[1] += color.g;
-                    lc.power[2] += color.b;
+                    lc.power[kTraceThreads] += color.g;
+                    lc.power[2 * kTraceThreads] += color.b;
                 }
                 RT_DIAG_TIC(depositStart);
                 if (Sink == kSinkProbe)
@@ -746,8 +781,8 @@ __global__ __launch_bounds__(kTraceThreads) void traceKernel(const TraceArgs a)
                     {
                         RT_DIAG_TRIP(10);
                         keep = anyProbeWithin(a.probes, hit.position);
-                        if (keep) lc.kept += 1;
-                        else lc.culled += 1;
+                        tally(lc, kTallyKept, keep);
+                        tally(lc, kTallyCulled, !keep);
                     }
                     storeAppend(a.store, keep, hit.position, ray.d, hit.normal, time, color);
                 }
@@ -755,8 +790,8 @@ __global__ __launch_bounds__(kTraceThreads) void traceKernel(const TraceArgs a)
                 {
                     if (a.density.enabled && !delta)
                     {
-                        lc.densityDeposits += 1;
-                        densityAdd(a.density, hit.position, color, lc.densityCells, lc.densityOverflow);
+                        tally(lc, kTallyDensityDeposits);
+                        densityAdd(a.density, hit.position, color, lc);
                     }
                     splatToCamera<Animated>(a, ray.d, color, bounces, lightId, time, hit, material, lc);
                 }
@@ -806,9 +841,7 @@ __global__ __launch_bounds__(kTraceThreads) void traceKernel(const TraceArgs a)
                     a.records.castsValid[2 * recordSlot + 0] = casts;
                     a.records.castsValid[2 * recordSlot + 1] = valid;
                 }
-                lc.photons += 1;
-                lc.casts += static_cast<uint32_t>(casts);
-                lc.bounces += static_cast<uint32_t>(valid);
+                tally(lc, kTallyPhotons);
                 alive = false;
             }
         }
@@ -848,23 +881,20 @@ __global__ __launch_bounds__(kTraceThreads) void traceKernel(const TraceArgs a)
     // ---- flush counters: one atomic per wave per counter ----
     RT_DIAG_TOC(kernelStart, 0);
     RT_DIAG_WAVE_END;
-    unsigned long long sums[12] = {lc.photons, lc.casts, lc.bounces, lc.deposits, lc.kept, lc.culled,
-                                   lc.splatTotal, lc.splatRadiusClamped, lc.splatLuminanceClamped,
-                                   lc.densityCells, lc.densityDeposits, lc.densityOverflow};
-    unsigned long long* dst = &a.counters->photons;
-#pragma unroll
-    for (int k = 0; k < 12; ++k)
+    static_assert(kTallySlots == 12 && offsetof(DeviceCounters, power) == 12 * sizeof(unsigned long long),
+                  "tally slots follow the layout of DeviceCounters");
+    if (lane < kTallySlots)
     {
-        const unsigned long long total = waveSum(sums[k]);
-        if (lane == 0 && total != 0)
+        const unsigned int counted = __hip_atomic_load(lc.slots + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (counted != 0)
         {
-            atomicAdd(dst + k, total);
+            atomicAdd(&a.counters->photons + lane, static_cast<unsigned long long>(counted));
         }
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k)
     {
-        const double total = waveSumD(lc.power[k]);
+        const double total = waveSumD(lc.power[k * kTraceThreads]);
         if (lane == 0 && total != 0.0)
         {
             atomicAdd(&a.counters->power[k], total);
@@ -1363,6 +1393,223 @@ __global__ __launch_bounds__(256) void gatherKernel(const GatherArgs a)
     }
 }
 
+// The same gather with G lanes (8 or 64) working on one pixel: where a gather point's footprint holds
+// hundreds of records (few camera pixels looking at a densely lit surface) one lane per pixel leaves
+// most of the chip idle and walks thousands of records in a row.  The G lanes of a group take G
+// consecutive records of a row of cells, each lane runs the tests and the BRDF of its record, and
+// the contributions that passed are then added in record order by every lane of the group alike —
+// the additions, and with them the rounding, are exactly those of the one-lane walk.
+template <int G>
+RT_DEV uint32_t groupBits(unsigned long long waveMask, int groupBase)
+{
+    return G == 64 ? 0u : static_cast<uint32_t>((waveMask >> groupBase) & ((1ull << (G & 63)) - 1));
+}
+
+template <int G>
+RT_DEV Color gatherRadianceGroup(const GatherArgs& a, const GatherPoint& gp, int member, int groupBase,
+                                 unsigned long long* deposits)
+{
+    const Color black{0.0f, 0.0f, 0.0f};
+    const bool isEmitter = gp.material < 0;
+    const Vec wo = mk(gp.viewDir[0], gp.viewDir[1], gp.viewDir[2]);
+    const Vec normal = mk(gp.normal[0], gp.normal[1], gp.normal[2]);
+    const Vec position = mk(gp.position[0], gp.position[1], gp.position[2]);
+    if (dot(wo, normal) <= 0.0)
+    {
+        return black;
+    }
+    const double r = (a.minGatherRadius > 0.0 && gp.footprintRadius < a.minGatherRadius) ? a.minGatherRadius
+                                                                                         : gp.footprintRadius;
+    if (r <= 0.0 || a.indexed == 0)
+    {
+        return black;
+    }
+    const double r2 = r * r;
+    const double planeBand = 2.0 * r;
+    const int64_t cx = static_cast<int64_t>(__builtin_floor(position.x * a.invCellSize));
+    const int64_t cy = static_cast<int64_t>(__builtin_floor(position.y * a.invCellSize));
+    const int64_t cz = static_cast<int64_t>(__builtin_floor(position.z * a.invCellSize));
+    const int64_t reach = static_cast<int64_t>(__builtin_ceil(r * a.invCellSize));
+    const int64_t x0 = clampCell(cx - reach), x1 = clampCell(cx + reach);
+    const int64_t y0 = clampCell(cy - reach), y1 = clampCell(cy + reach);
+    const int64_t z0 = clampCell(cz - reach), z1 = clampCell(cz + reach);
+    if (cx + reach < -kPackLimit || cx - reach >= kPackLimit || cy + reach < -kPackLimit || cy - reach >= kPackLimit ||
+        cz + reach < -kPackLimit || cz - reach >= kPackLimit)
+    {
+        return black;
+    }
+    const Material* material = isEmitter ? nullptr : &a.scene.materials[gp.material];
+    Color sum = black;
+    unsigned long long kept = 0;
+    const bool bySlab = (y1 - y0) > 16;  // as in gatherRadiance
+    for (int64_t z = z0; z <= z1; ++z)
+    {
+        for (int64_t y = y0; y <= y1; ++y)
+        {
+            const unsigned long long first = packCell(x0, y, z);
+            const unsigned long long last = bySlab ? packCell(x1, y1, z) : packCell(x1, y, z);
+            for (uint64_t base = lowerBound(a.keys, a.indexed, first);; base += G)
+            {
+                typedef float Float4At4 __attribute__((ext_vector_type(4), aligned(4)));
+                const uint64_t j = base + static_cast<uint64_t>(member);
+                const bool inside = j < a.indexed;
+                const uint64_t at = inside ? j : a.indexed - 1;
+                const float* row = a.store + 13ull * at;
+                const unsigned long long key = a.keys[at];
+                const Float4At4 q0 = *reinterpret_cast<const Float4At4*>(row);
+                const Float4At4 q1 = *reinterpret_cast<const Float4At4*>(row + 4);
+                const Float4At4 q2 = *reinterpret_cast<const Float4At4*>(row + 8);
+                const float q3 = row[12];
+                const bool beyond = !inside || key > last;
+                bool passes = !beyond;
+                if (passes && bySlab)
+                {
+                    const int64_t kx = static_cast<int64_t>(key & ((1ull << 21) - 1)) - kPackLimit;
+                    passes = kx >= x0 && kx <= x1;
+                }
+                Color contribution = black;
+                if (passes)
+                {
+                    const double ddx = static_cast<double>(q0.x) - position.x;
+                    const double ddy = static_cast<double>(q0.y) - position.y;
+                    const double ddz = static_cast<double>(q0.z) - position.z;
+                    passes = ddx * ddx + ddy * ddy + ddz * ddz <= r2;
+                }
+                if (passes)
+                {
+                    const float time = q2.y;
+                    if (!__builtin_isinf(time) || time < 0.0f)  // +inf marks a timeless (emitter) deposit
+                    {
+                        passes = !(__builtin_fabsf(time - gp.sampleTime) > a.timeHalfWindow);
+                    }
+                }
+                if (passes)
+                {
+                    const Vec dn = mk(q1.z, q1.w, q2.x);
+                    const Color power{q2.z, q2.w, q3};
+                    if (isEmitter)
+                    {
+                        passes = !(dot(dn, normal) < 0.5);
+                        contribution = power;
+                    }
+                    else
+                    {
+                        const double dnLen = magnitude(dn);
+                        if (dnLen > 1e-4)
+                        {
+                            passes = !(dot(dn / dnLen, normal) < 0.5);
+                        }
+                        if (passes)
+                        {
+                            const double planeDist = dabs(dot(mk(q0.x, q0.y, q0.z) - position, normal));
+                            passes = !(planeDist > planeBand);
+                        }
+                        if (passes)
+                        {
+                            const Vec wi = neg(mk(q0.w, q1.x, q1.y));
+                            contribution = evaluateMaterial(*material, wi, wo, normal) * power;
+                        }
+                    }
+                }
+                // the group's verdicts, then the additions in record order
+                const unsigned long long passMask = __ballot(passes), beyondMask = __ballot(beyond);
+                if (G == 64)
+                {
+                    unsigned long long todo = passMask;
+                    kept += static_cast<unsigned long long>(__builtin_popcountll(todo));
+                    while (todo != 0)
+                    {
+                        const int k = __builtin_ctzll(todo);
+                        todo &= todo - 1;
+                        sum.r += __shfl(contribution.r, k, 64);
+                        sum.g += __shfl(contribution.g, k, 64);
+                        sum.b += __shfl(contribution.b, k, 64);
+                    }
+                    if (beyondMask != 0) break;
+                }
+                else
+                {
+                    uint32_t todo = groupBits<G>(passMask, groupBase);
+                    kept += static_cast<unsigned long long>(__builtin_popcount(todo));
+                    while (todo != 0)
+                    {
+                        const int k = __builtin_ctz(todo);
+                        todo &= todo - 1;
+                        sum.r += __shfl(contribution.r, k, G);
+                        sum.g += __shfl(contribution.g, k, G);
+                        sum.b += __shfl(contribution.b, k, G);
+                    }
+                    if (groupBits<G>(beyondMask, groupBase) != 0) break;
+                }
+            }
+            if (bySlab)
+            {
+                break;  // the slab scan covered every row of this z
+            }
+        }
+    }
+    *deposits = kept;
+    if (kept == 0)
+    {
+        return black;
+    }
+    const double area = kPi * r * r;
+    const float scale = static_cast<float>((4.0 / kPi) / area);
+    return sum * scale;
+}
+
+template <int G>
+__global__ __launch_bounds__(256) void gatherGroupKernel(const GatherArgs a)
+{
+    const int64_t thread = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const int64_t i = thread / G;
+    const int member = static_cast<int>(thread % G);
+    const int groupBase = static_cast<int>(threadIdx.x & 63) - member;
+    unsigned long long added = 0, depositsAccum = 0;
+    if (i < a.pixels && a.counts[i] != 0)
+    {
+        const Camera& cam = a.scene.cameras[a.camera];
+        const GatherPoint* points = a.points + a.offsets[i];
+        Color acc{0.0f, 0.0f, 0.0f};
+        for (uint32_t k = 0; k < a.counts[i]; ++k)
+        {
+            const GatherPoint& gp = points[k];
+            if (gp.material >= a.scene.materialCount)
+            {
+                continue;
+            }
+            unsigned long long deposits = 0;
+            const Color radiance = gatherRadianceGroup<G>(a, gp, member, groupBase, &deposits);
+            const Color throughput{gp.throughput[0], gp.throughput[1], gp.throughput[2]};
+            const Color contribution = throughput * radiance * gp.sampleWeight;
+            depositsAccum += deposits;
+            if (contribution.r == 0.0f && contribution.g == 0.0f && contribution.b == 0.0f)
+            {
+                continue;
+            }
+            acc.r += contribution.r;
+            acc.g += contribution.g;
+            acc.b += contribution.b;
+            added += 1;
+        }
+        const uint64_t w = static_cast<uint64_t>(cam.width), h = static_cast<uint64_t>(cam.height);
+        const uint64_t at = ((static_cast<uint64_t>(points[0].py) * w) + static_cast<uint64_t>(points[0].px)) * 3;
+        if (member == 0 && added != 0 && at + 2 < w * h * 3)
+        {
+            atomicAdd(cam.buffer + at + 0, acc.r);
+            atomicAdd(cam.buffer + at + 1, acc.g);
+            atomicAdd(cam.buffer + at + 2, acc.b);
+        }
+    }
+    // every lane of a group carries the group's tallies: count them once
+    const unsigned long long totals[2] = {waveSum(member == 0 ? added : 0ull), waveSum(member == 0 ? depositsAccum : 0ull)};
+    if ((threadIdx.x & 63) == 0)
+    {
+        if (totals[0] != 0) atomicAdd(a.stats + 0, totals[0]);
+        if (totals[1] != 0) atomicAdd(a.stats + 1, totals[1]);
+    }
+}
+
 // ---------------------------------------------------------------- emitter deposits
 // ProbeGather::depositEmitters, reference src/ProbeGather.cpp:464-550: sample (iu, iv) of a
 // patch's grid, or no sample when it falls outside a disc.  The arithmetic is the reference's.
@@ -1642,7 +1889,7 @@ TraceKernel traceVariant(const TraceArgs& args)
 
 size_t traceLdsBytes(const SceneView& scene)
 {
-    return stackBytes(scene, kTraceThreads);
+    return stackBytes(scene, kTraceThreads) + scene.cacheBytes;
 }
 
 }  // namespace
@@ -1662,10 +1909,29 @@ hipError_t sortEmissionPairs(void* scratch, size_t* scratchBytes, const uint32_t
                                               2 * kGlobalAxisBits + lightBits, stream);
 }
 
-void launchTrace(const TraceArgs& args, int blocks, int threads, hipStream_t stream)
+int traceBlockThreads() { return kTraceThreads; }
+
+size_t traceCacheBudget(int stackDepth)
 {
-    (void)threads;
-    hipLaunchKernelGGL(traceVariant(args), dim3(blocks), dim3(kTraceThreads), traceLdsBytes(args.scene), stream, args);
+    // all of a CU's LDS but the stacks and a margin (the census builds keep a few words of their own)
+    const size_t total = 160 * 1024 / (512 / kTraceThreads), margin = 8192;
+    const size_t stacks = static_cast<size_t>(stackDepth > 0 ? stackDepth : 1) * kTraceThreads * sizeof(unsigned long long);
+    return stacks + margin < total ? (total - stacks - margin) & ~static_cast<size_t>(63) : 0;
+}
+
+hipError_t launchTrace(const TraceArgs& args, int blocks, hipStream_t stream)
+{
+    const TraceKernel kernel = traceVariant(args);
+    const size_t lds = traceLdsBytes(args.scene);
+    if (lds > 64 * 1024)
+    {
+        // more dynamic LDS than a kernel gets by default has to be asked for, once per kernel
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 static_cast<int>(lds));
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kTraceThreads), lds, stream, args);
+    return hipGetLastError();
 }
 
 // Resident blocks per CU of the variant this pass runs (registers and LDS differ between them;
@@ -1770,10 +2036,21 @@ void launchReorderStore(const float* store, const uint32_t* order, uint64_t inde
                        order, floats, sorted);
 }
 
-void launchGather(const GatherArgs& args, hipStream_t stream)
+void launchGather(const GatherArgs& args, int lanesPerPixel, hipStream_t stream)
 {
     if (args.pixels <= 0) return;
-    hipLaunchKernelGGL(gatherKernel, dim3(gridFor(args.pixels)), dim3(256), 0, stream, args);
+    if (lanesPerPixel >= 64)
+    {
+        hipLaunchKernelGGL(gatherGroupKernel<64>, dim3(gridFor(args.pixels * 64)), dim3(256), 0, stream, args);
+    }
+    else if (lanesPerPixel >= 8)
+    {
+        hipLaunchKernelGGL(gatherGroupKernel<8>, dim3(gridFor(args.pixels * 8)), dim3(256), 0, stream, args);
+    }
+    else
+    {
+        hipLaunchKernelGGL(gatherKernel, dim3(gridFor(args.pixels)), dim3(256), 0, stream, args);
+    }
 }
 
 void launchEmitterCount(const EmitterGrid& grid, unsigned long long* count, hipStream_t stream)

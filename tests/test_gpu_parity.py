@@ -405,14 +405,19 @@ GATHER_SCENES = {
 }
 
 
+@pytest.mark.parametrize("lanes", [0, 1, 8, 64])
 @pytest.mark.parametrize("name", sorted(GATHER_SCENES))
-def test_gather_equals_oracle(rt, scene_opener, name):
-    """The whole probe-mode frame after the photon pass.  (1) Given the SAME store, record for
+def test_gather_equals_oracle(rt, scene_opener, name, lanes, monkeypatch):
+    """(The gather gives a sampled pixel 1, 8 or 64 lanes by how dense the store is: 0 lets it choose, the
+    other values force each form; the result may not depend on it by a single bit.)
+    The whole probe-mode frame after the photon pass.  (1) Given the SAME store, record for
     record in the same order, the device gather (sort by cell, one thread per pixel) returns
     the oracle's camera buffers bit for bit.  (2) The device's own frame (emitter deposits
     pre-loaded, photon pass, gather) holds the same store as a multiset and the same image up
     to the rounding of a different float summation order (the reference's own result depends
     on append order the same way when it runs more than one worker)."""
+    if lanes:
+        monkeypatch.setenv("RT_AMD_GATHER_LANES", str(lanes))
     scene, tracer, orc = _open(rt, scene_opener, GATHER_SCENES[name])
     setup = O.frame_setup(orc, O.RNG_COUNTER, O.MATH_PORTABLE)
     keep = setup["keep_radius"]
