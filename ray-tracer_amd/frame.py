@@ -1,13 +1,6 @@
-"""Frame-level glue around the tracer: sink set-up as Renderer::renderFrame does it
-(reference src/Renderer.cpp:222-419) and the CPU baseline leg of bench.py."""
+"""Frame-level glue around the tracer: sink set-up and the sharded frame as Renderer::renderFrame
+does them (reference src/Renderer.cpp:222-419)."""
 import ctypes as C
-import json
-import os
-import subprocess
-import tempfile
-import time
-
-import numpy as np
 
 
 def derive(rt, scene):
@@ -66,13 +59,15 @@ def render_frame(rt, scene, tracer, buffers, rank=0, world=1, dist=None):
         tracer.reset()
         if rank == 0:
             tracer.deposit_emitters(max(cell * 0.5, 1e-6))
-        tracer.trace(sink_mode=rt.tracer.SINK_PROBE, first_photon=first, photon_count=count)
+        if count > 0:  # an empty share traces nothing (a count of 0 would mean "all the rest")
+            tracer.trace(sink_mode=rt.tracer.SINK_PROBE, first_photon=first, photon_count=count)
         for c in gathering:
             tracer.gather(c, cell, d["min_splat_radius"])
     else:
         prepare_sinks(rt, scene, tracer, "splat")
         tracer.reset()
-        tracer.trace(sink_mode=rt.tracer.SINK_SPLAT, first_photon=first, photon_count=count)
+        if count > 0:
+            tracer.trace(sink_mode=rt.tracer.SINK_SPLAT, first_photon=first, photon_count=count)
     counters = tracer.counters()  # waits for the stream
     parallel.all_reduce_sum(list(buffers), dist)
     names = ("photons", "casts", "bounces", "deposits", "kept", "culled", "store_attempted", "store_size", "splat_total")
@@ -82,58 +77,3 @@ def render_frame(rt, scene, tracer, buffers, rank=0, world=1, dist=None):
         parallel.all_reduce_sum([totals], dist)
         counters = dict(counters, **dict(zip(names, (int(v) for v in totals.tolist()))))
     return counters
-
-
-def cpu_baseline(rt, scene_path, sink, setup, photons):
-    """Time the CPU path on a bounded sample of the same workload (same scene, `photons`
-    photons per light instead of the full budget; cost is linear in photons).
-
-    Preferred: the REFERENCE itself (oracle/_ref/refdump bench, its own multithreaded
-    Worker loop, photonPassSeconds as it reports it); its bounce count comes from the
-    oracle run at the same photon count (the reference does not count delta bounces).
-    Fallback: the oracle port."""
-    import oracle_lib as O
-
-    cores = min(16, os.cpu_count() or 1)
-    scene = rt.Scene(scene_path)
-    scene.settings.photons_per_light = photons
-    orc = O.Oracle(scene)
-    kwargs = {}
-    if sink == "probe":
-        kwargs = dict(sink_mode=O.SINK_PROBE, probes=setup["probes"], probe_cell_size=setup["keep_radius"],
-                      keep_radius=setup["keep_radius"], store_capacity=setup["store_capacity"])
-    elif sink == "splat":
-        kwargs = dict(sink_mode=O.SINK_SPLAT, min_splat_radius=setup["min_splat_radius"],
-                      density_cell_size=setup["cell_size"])
-    t0 = time.perf_counter()
-    r = orc.trace(rng_mode=O.RNG_COUNTER, math_mode=O.MATH_PORTABLE, threads=cores, **kwargs)
-    port_seconds = time.perf_counter() - t0
-    result = {
-        "value": r["bounces"] / port_seconds, "unit": "photon-bounces/s", "cores": cores, "kind": "port",
-        "sample": f"{photons} photons per light of the same scene ({r['bounces']} bounces, {port_seconds:.2f} s), "
-                  f"oracle/liboracle.so with {cores} threads",
-    }
-    refdump = os.path.join(rt.REPO_ROOT, "oracle", "_ref", "refdump")
-    if os.path.exists(refdump):
-        try:
-            with tempfile.TemporaryDirectory() as tmp:
-                blob = os.path.join(tmp, "scene.rtsb")
-                scene.settings.use_probe_gather = 1 if sink == "probe" else 0
-                scene.settings.worker_count = cores
-                scene.write(blob)
-                proc = subprocess.run([refdump, "bench", blob, str(cores)], capture_output=True, text=True,
-                                      timeout=600, check=True)
-                line = [l for l in proc.stdout.splitlines() if l.startswith("{")][-1]
-                ref = json.loads(line)
-                result = {
-                    "value": r["bounces"] / ref["photon_pass_seconds"], "unit": "photon-bounces/s", "cores": cores,
-                    "kind": "reference",
-                    "sample": f"{photons} photons per light of the same scene; the reference's own Worker path "
-                              f"(oracle/_ref/refdump bench, {cores} workers) took photonPassSeconds="
-                              f"{ref['photon_pass_seconds']:.2f} (includes its single-threaded probe pass); "
-                              f"{r['bounces']} bounces counted by the oracle at the same photon count",
-                    "port_value": r["bounces"] / port_seconds,
-                }
-        except Exception as e:  # the reference binary is optional on the GPU box
-            result["reference_error"] = str(e)[:200]
-    return result
