@@ -647,6 +647,8 @@ void buildScene(rt_tracer* t, const rt_scene* scene)
     {
         const rt_camera& rc = scene->cameras[i];
         require(rc.width > 0 && rc.height > 0, "camera resolution must be positive");
+        require(static_cast<uint64_t>(rc.width) * static_cast<uint64_t>(rc.height) * 3 < (1ull << 32),
+                "camera buffer too large (its float index must fit 32 bits)");
         rtd::Camera c{};
         std::memcpy(c.pos, rc.position, sizeof(c.pos));
         const double ux[3] = {1, 0, 0}, uy[3] = {0, 1, 0}, uz[3] = {0, 0, 1};

@@ -393,15 +393,68 @@ RT_DEV void densityAdd(const DensityView& dv, const Vec& p, const Color& power, 
     tally(lc, kTallyDensityOverflow);
 }
 
+// Buffer::addColor (reference src/Buffer.cpp:22-37) for the lanes of a wave at once.  Photons that
+// left the light together land in the same few pixels: the lanes that add to the same pixel are found
+// with ballots (the lowest pending lane names its pixel, the lanes with that pixel answer), their
+// contributions are added up in lane order, and one lane issues the three atomics for all of them.  A
+// pixel only one lane adds to costs the ballots and nothing else.  Every lane of the wave that is
+// active at the call takes part; `emit` says whether it has something to add.
+RT_DEV void addToPixels(float* buffer, bool emit, uint32_t index, const Color& contribution)
+{
+    unsigned long long pending = __ballot(emit);
+    // A wave whose lanes all add to different pixels (a large image, photons deep in their paths) would
+    // go round once per lane for nothing: after a few rounds the lanes still pending add on their own.
+    constexpr int kRounds = 6;
+    for (int round = 0; pending != 0; ++round)
+    {
+        const int leader = __builtin_ctzll(pending);
+        const uint32_t pixel = __shfl(index, leader, 64);
+        const bool same = emit && index == pixel;
+        unsigned long long members = __ballot(same);
+        const bool lastRound = round == kRounds - 1;
+        const bool alone = (members & (members - 1)) == 0;
+        if (lastRound || alone)
+        {
+            if (lastRound ? (emit && ((pending >> (threadIdx.x & 63)) & 1) != 0) : same)
+            {
+                atomicAdd(buffer + index + 0, contribution.r);
+                atomicAdd(buffer + index + 1, contribution.g);
+                atomicAdd(buffer + index + 2, contribution.b);
+            }
+            if (lastRound) break;
+            pending &= ~members;
+            continue;
+        }
+        pending &= ~members;
+        float r = 0.0f, g = 0.0f, b = 0.0f;
+        while (members != 0)
+        {
+            const int k = __builtin_ctzll(members);
+            members &= members - 1;
+            r += __shfl(contribution.r, k, 64);
+            g += __shfl(contribution.g, k, 64);
+            b += __shfl(contribution.b, k, 64);
+        }
+        if (static_cast<int>(threadIdx.x & 63) == leader)
+        {
+            atomicAdd(buffer + pixel + 0, r);
+            atomicAdd(buffer + pixel + 1, g);
+            atomicAdd(buffer + pixel + 2, b);
+        }
+    }
+}
+
 // Worker::splatToCamera, reference src/Worker.cpp:221-427, with
 // Camera::coordForPointSubPixel (src/Camera.cpp:239-310), Utility::flooredSplatRadius
-// (src/Utility.cpp:43-50) and Buffer::addColor (src/Buffer.cpp:22-37).
+// (src/Utility.cpp:43-50) and Buffer::addColor (src/Buffer.cpp:22-37).  Every lane that is active at
+// the call goes through every camera (the pixel sums are formed across the wave); `splats` is false
+// for a lane whose hit deposits nothing (a delta surface).
 template <bool Animated>
-RT_DEV void splatToCamera(const TraceArgs& a, const Vec& incoming, const Color& photonColor, int bounces, int lightId,
-                          float time, const Hit& hit, const Material& material, const WaveTally& lc)
+RT_DEV void splatToCamera(const TraceArgs& a, bool splats, const Vec& incoming, const Color& photonColor, int bounces,
+                          int lightId, float time, const Hit& hit, const Material& material, const WaveTally& lc)
 {
     const SceneView& s = a.scene;
-    if (materialIsDelta(material.type) || static_cast<double>(s.photonsPerLight) <= 0.0)
+    if (static_cast<double>(s.photonsPerLight) <= 0.0)
     {
         return;
     }
@@ -409,72 +462,82 @@ RT_DEV void splatToCamera(const TraceArgs& a, const Vec& incoming, const Color& 
     for (int32_t c = 0; c < s.cameraCount; ++c)
     {
         const Camera& cam = s.cameras[c];
-        if (cam.bounceFilter >= 0 && bounces != cam.bounceFilter) continue;
-        if (cam.lightFilter >= 0 && lightId != cam.lightFilter) continue;
-        if (cam.width <= 0 || cam.height <= 0) continue;
-        const Vec eye = mk(cam.pos[0], cam.pos[1], cam.pos[2]);
-        const Vec toPoint = hit.position - eye;
-        const double depth = dot(toPoint, mk(cam.forward[0], cam.forward[1], cam.forward[2]));
-        if (depth <= 0.0) continue;
-        if (cam.halfHeight <= 0.0) continue;
-        const double dx = dot(toPoint, mk(cam.right[0], cam.right[1], cam.right[2]));
-        const double dy = dot(toPoint, mk(cam.up[0], cam.up[1], cam.up[2]));
-        const double sx = (dx / depth) / (cam.aspect * cam.halfHeight);
-        const double sy = (dy / depth) / cam.halfHeight;
-        if (sx < -1.0 || sx > 1.0 || sy < -1.0 || sy > 1.0) continue;
-        const double subX = ((sx + 1.0) / 2.0) * static_cast<double>(cam.width);
-        const double subY = ((sy + 1.0) / 2.0) * static_cast<double>(cam.height);
+        if (cam.width <= 0 || cam.height <= 0 || cam.halfHeight <= 0.0) continue;  // the same for every lane
         const uint64_t w = static_cast<uint64_t>(cam.width), h = static_cast<uint64_t>(cam.height);
-        uint64_t px = static_cast<uint64_t>(dmax(0.0, __builtin_floor(subX)));
-        uint64_t py = static_cast<uint64_t>(dmax(0.0, __builtin_floor(subY)));
-        px = px < w - 1 ? px : w - 1;
-        py = py < h - 1 ? py : h - 1;
-
-        if (!(time >= cam.windowStart && time < cam.windowEnd)) continue;
-
-        const Vec toCamera = eye - hit.position;
-        const double cameraDistance = magnitude(toCamera);
-        if (cameraDistance < kSelfHitThreshold) continue;
-        const Vec toCameraDir = toCamera / cameraDistance;
-        const double cosCamera = dot(toCameraDir, hit.normal);
-        if (cosCamera <= 0.0) continue;
-
-        Ray shadow;
-        shadow.o = hit.position;
-        shadow.d = toCameraDir;
-        Hit occluder;
-        if (castScene<Animated, true>(s, shadow, time, kSelfHitThreshold, false, &occluder) && occluder.distance < cameraDistance)
+        bool emit = splats;
+        if (cam.bounceFilter >= 0 && bounces != cam.bounceFilter) emit = false;
+        if (cam.lightFilter >= 0 && lightId != cam.lightFilter) emit = false;
+        uint32_t index = 0;
+        Color clamped{0.0f, 0.0f, 0.0f};
+        if (emit)
         {
-            continue;
-        }
-
-        const double rawRadius = cameraDistance * cam.tanPixelHalfAngle;
-        const double r = (a.minSplatRadius > 0.0 && rawRadius < a.minSplatRadius) ? a.minSplatRadius : rawRadius;
-        tally(lc, kTallySplatTotal);
-        tally(lc, kTallySplatRadiusClamped, r > rawRadius);
-        if (r <= 0.0) continue;
-
-        const Color brdf = evaluateMaterial(material, wi, toCameraDir, hit.normal);
-        const double area = kPi * r * r;
-        const float scale = static_cast<float>(cosCamera / area);
-        const Color contribution = brdf * photonColor * scale;
-        if (brightness(contribution) <= 0.0f) continue;
-
-        Color clamped = contribution;
-        if (s.splatLuminanceClamp > 0.0)
-        {
-            const double b = static_cast<double>(brightness(contribution));
-            if (b > s.splatLuminanceClamp)
+            emit = false;
+            do
             {
-                clamped = contribution * static_cast<float>(s.splatLuminanceClamp / b);
-                tally(lc, kTallySplatLuminanceClamped);
-            }
+                const Vec eye = mk(cam.pos[0], cam.pos[1], cam.pos[2]);
+                const Vec toPoint = hit.position - eye;
+                const double depth = dot(toPoint, mk(cam.forward[0], cam.forward[1], cam.forward[2]));
+                if (depth <= 0.0) break;
+                const double dx = dot(toPoint, mk(cam.right[0], cam.right[1], cam.right[2]));
+                const double dy = dot(toPoint, mk(cam.up[0], cam.up[1], cam.up[2]));
+                const double sx = (dx / depth) / (cam.aspect * cam.halfHeight);
+                const double sy = (dy / depth) / cam.halfHeight;
+                if (sx < -1.0 || sx > 1.0 || sy < -1.0 || sy > 1.0) break;
+                const double subX = ((sx + 1.0) / 2.0) * static_cast<double>(cam.width);
+                const double subY = ((sy + 1.0) / 2.0) * static_cast<double>(cam.height);
+                uint64_t px = static_cast<uint64_t>(dmax(0.0, __builtin_floor(subX)));
+                uint64_t py = static_cast<uint64_t>(dmax(0.0, __builtin_floor(subY)));
+                px = px < w - 1 ? px : w - 1;
+                py = py < h - 1 ? py : h - 1;
+
+                if (!(time >= cam.windowStart && time < cam.windowEnd)) break;
+
+                const Vec toCamera = eye - hit.position;
+                const double cameraDistance = magnitude(toCamera);
+                if (cameraDistance < kSelfHitThreshold) break;
+                const Vec toCameraDir = toCamera / cameraDistance;
+                const double cosCamera = dot(toCameraDir, hit.normal);
+                if (cosCamera <= 0.0) break;
+
+                Ray shadow;
+                shadow.o = hit.position;
+                shadow.d = toCameraDir;
+                Hit occluder;
+                if (castScene<Animated, true>(s, shadow, time, kSelfHitThreshold, false, &occluder) &&
+                    occluder.distance < cameraDistance)
+                {
+                    break;
+                }
+
+                const double rawRadius = cameraDistance * cam.tanPixelHalfAngle;
+                const double r = (a.minSplatRadius > 0.0 && rawRadius < a.minSplatRadius) ? a.minSplatRadius : rawRadius;
+                tally(lc, kTallySplatTotal);
+                tally(lc, kTallySplatRadiusClamped, r > rawRadius);
+                if (r <= 0.0) break;
+
+                const Color brdf = evaluateMaterial(material, wi, toCameraDir, hit.normal);
+                const double area = kPi * r * r;
+                const float scale = static_cast<float>(cosCamera / area);
+                const Color contribution = brdf * photonColor * scale;
+                if (brightness(contribution) <= 0.0f) break;
+
+                clamped = contribution;
+                if (s.splatLuminanceClamp > 0.0)
+                {
+                    const double b = static_cast<double>(brightness(contribution));
+                    if (b > s.splatLuminanceClamp)
+                    {
+                        clamped = contribution * static_cast<float>(s.splatLuminanceClamp / b);
+                        tally(lc, kTallySplatLuminanceClamped);
+                    }
+                }
+                const uint64_t at = ((py * w) + px) * 3;
+                if (at + 2 >= w * h * 3) break;
+                index = static_cast<uint32_t>(at);
+                emit = true;
+            } while (false);
         }
-        const uint64_t index = ((py * w) + px) * 3;
-        if (index + 2 >= w * h * 3) continue;
-        atomicAdd(cam.buffer + index + 0, clamped.r);
-        atomicAdd(cam.buffer + index + 1, clamped.g);
-        atomicAdd(cam.buffer + index + 2, clamped.b);
+        addToPixels(cam.buffer, emit, index, clamped);
     }
 }
 
@@ -793,7 +856,7 @@ __global__ __launch_bounds__(kTraceThreads) void traceKernel(const TraceArgs a)
                         tally(lc, kTallyDensityDeposits);
                         densityAdd(a.density, hit.position, color, lc);
                     }
-                    splatToCamera<Animated>(a, ray.d, color, bounces, lightId, time, hit, material, lc);
+                    splatToCamera<Animated>(a, !delta, ray.d, color, bounces, lightId, time, hit, material, lc);
                 }
 
                 RT_DIAG_TOC(depositStart, 5);
