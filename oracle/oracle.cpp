@@ -1111,6 +1111,10 @@ struct orc_context
     std::vector<std::vector<float>> splatPlain;
     std::vector<const float*> splatPointers;
     std::vector<double> gatherRows;
+    // camera-side passes visit the pixels x0 <= x < x1, y0 <= y < y1 only (tests that check a crop of
+    // a large frame; every pixel has its own counter stream, so a pixel's records do not depend on
+    // which other pixels are visited — with the sequential mt19937 stream they do)
+    std::int64_t window[4] = {0, 0, INT64_MAX, INT64_MAX};
 };
 
 namespace
@@ -2035,6 +2039,11 @@ std::vector<GatherPoint> collectGatherPoints(const orc_context& ctx, int cameraI
     {
         for (size_t x = 0; x < static_cast<size_t>(cam.d.width); x += stride)
         {
+            if (static_cast<std::int64_t>(x) < ctx.window[0] || static_cast<std::int64_t>(y) < ctx.window[1] ||
+                static_cast<std::int64_t>(x) >= ctx.window[2] || static_cast<std::int64_t>(y) >= ctx.window[3])
+            {
+                continue;
+            }
             if (rngMode == ORC_RNG_MT)
             {
                 collectPixel<M>(ctx, cam, patches, x, y, mt, []() { return MtRng(0xC0FFEEu); }, castBuffer, points,
@@ -2183,6 +2192,14 @@ orc_context* orc_create(const rt_scene* scene)
 }
 
 void orc_destroy(orc_context* ctx) { delete ctx; }
+
+void orc_set_pixel_window(orc_context* ctx, std::int64_t x0, std::int64_t y0, std::int64_t x1, std::int64_t y1)
+{
+    ctx->window[0] = x0;
+    ctx->window[1] = y0;
+    ctx->window[2] = x1;
+    ctx->window[3] = y1;
+}
 
 void orc_derive(const orc_context* ctx, double out[4])
 {

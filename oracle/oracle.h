@@ -116,6 +116,12 @@ void orc_emit(const orc_context* ctx, int32_t light, int64_t n, const double* dr
 void orc_emit_mt(const orc_context* ctx, int32_t light, int64_t n, uint32_t seed,
                  uint64_t total_photons, double* rays, float* colors);
 
+/* Test aid: the camera-side passes (orc_collect_gather_points, orc_gather) visit only the pixels
+ * x0 <= x < x1, y0 <= y < y1 of every camera — a crop of a frame too large to restate whole.  In
+ * counter mode a pixel's records do not depend on the window (one stream per pixel); in mt19937 mode
+ * they do (one sequential stream), so the window is for counter mode. */
+void orc_set_pixel_window(orc_context* ctx, int64_t x0, int64_t y0, int64_t x1, int64_t y1);
+
 /* Probe pass (ProbeGather::collectGatherPoints, src/ProbeGather.cpp:239-460) for one
  * camera; rows of 19 doubles as refdump's `probes` mode.  Returns the row count and
  * keeps the array owned by the context. */

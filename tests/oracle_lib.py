@@ -56,6 +56,8 @@ def lib():
         L.orc_emit.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p,
                                C.c_void_p]
         L.orc_emit_mt.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p]
+        L.orc_set_pixel_window.restype = None
+        L.orc_set_pixel_window.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64]
         L.orc_collect_gather_points.restype = C.c_int64
         L.orc_collect_gather_points.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                                 C.POINTER(C.POINTER(C.c_double))]
@@ -126,6 +128,10 @@ class Oracle:
         colors = np.zeros((n, 3), dtype=np.float32)
         lib().orc_emit_mt(self.ctx, light, n, seed, total_photons, _ptr(rays), _ptr(colors))
         return rays, colors
+
+    def set_pixel_window(self, x0, y0, x1, y1):
+        """Camera-side passes visit only pixels x0 <= x < x1, y0 <= y < y1 (counter mode: per-pixel streams)."""
+        lib().orc_set_pixel_window(self.ctx, x0, y0, x1, y1)
 
     def collect_gather_points(self, camera=0, rng_mode=RNG_COUNTER, math_mode=MATH_PORTABLE):
         """(rows[n, 19], stats) of the probe pass restatement (ProbeGather::collectGatherPoints)."""
