@@ -36,6 +36,15 @@ void rth_scene_free(rth_scene* scene);
  * size, [2] minimum splat radius, [3] probe keep radius. */
 int rth_frame_derive(const rt_scene* scene, double out[4]);
 
+/* Material::sample / evaluate / pdf / isDelta of material `material` of the scene's library
+ * (reference include/Material.h:56-101), run through the host classes' virtuals — which evaluate the
+ * device's BSDFs (needs a GPU).  sample: in6 = incident, normal; the draws come from a
+ * RandomGenerator(seed) (mt19937, reference src/RandomGenerator.cpp:3-17); out9 = valid,
+ * direction[3], weight[3], pdf, number of draws consumed.  evaluate: in9 = wi, wo, normal;
+ * out5 = f[3], pdf, isDelta. */
+int rth_material_sample(const rth_scene* scene, int32_t material, const double in6[6], uint32_t seed, double out9[9]);
+int rth_material_evaluate(const rth_scene* scene, int32_t material, const double in9[9], double out5[5]);
+
 /* The CLI's image writer (reference src/PngWriter.cpp, src/PngWriteSession.cpp:118-173):
  * rgb[height][width][3] as a 16-bit RGB PNG with a "Title" text chunk when title is not empty. */
 int rth_write_png16(const char* path, const uint16_t* rgb, int32_t width, int32_t height, const char* title);

@@ -42,6 +42,9 @@ def host_lib():
         lib.rth_scene_write.argtypes = [_C.c_void_p, _C.c_char_p]
         lib.rth_scene_free.argtypes = [_C.c_void_p]
         lib.rth_write_png16.argtypes = [_C.c_char_p, _C.c_void_p, _C.c_int32, _C.c_int32, _C.c_char_p]
+        lib.rth_material_sample.argtypes = [_C.c_void_p, _C.c_int32, _C.POINTER(_C.c_double), _C.c_uint32,
+                                            _C.POINTER(_C.c_double)]
+        lib.rth_material_evaluate.argtypes = [_C.c_void_p, _C.c_int32, _C.POINTER(_C.c_double), _C.POINTER(_C.c_double)]
         _host = lib
     return _host
 
@@ -69,6 +72,23 @@ class Scene:
     @property
     def settings(self):
         return host_lib().rth_scene_settings(self._handle).contents
+
+    def material_sample(self, material, incident, normal, seed):
+        """Material::sample of the scene's material `material` with draws from RandomGenerator(seed):
+        (valid, direction[3], weight[3], pdf, draws consumed)."""
+        rows = (_C.c_double * 6)(*incident, *normal)
+        out = (_C.c_double * 9)()
+        if host_lib().rth_material_sample(self._handle, material, rows, seed, out) != 0:
+            raise RuntimeError(host_lib().rth_last_error().decode())
+        return list(out)
+
+    def material_evaluate(self, material, wi, wo, normal):
+        """Material::evaluate / pdf / isDelta: (f[3], pdf, isDelta)."""
+        rows = (_C.c_double * 9)(*wi, *wo, *normal)
+        out = (_C.c_double * 5)()
+        if host_lib().rth_material_evaluate(self._handle, material, rows, out) != 0:
+            raise RuntimeError(host_lib().rth_last_error().decode())
+        return list(out)
 
     def write(self, path):
         if host_lib().rth_scene_write(self._handle, str(path).encode()) != 0:

@@ -143,13 +143,15 @@ void flattenScene(const LoadedScene& loaded, FlatScene& out)
     for (size_t i = 0; i < loaded.materialLibrary->size(); ++i)
     {
         const std::shared_ptr<Material> m = loaded.materialLibrary->fetchByIndex(i);
+        // what the device runs for it: the material's own description (Material::deviceDescription)
+        const DeviceMaterial d = m->deviceDescription();
         rt_material rm{};
-        rm.type = static_cast<int32_t>(m->kind());
-        rm.color[0] = m->color().red;
-        rm.color[1] = m->color().green;
-        rm.color[2] = m->color().blue;
-        rm.alpha = m->alpha();
-        rm.ior = m->ior();
+        rm.type = static_cast<int32_t>(d.bsdf);
+        rm.color[0] = d.color.red;
+        rm.color[1] = d.color.green;
+        rm.color[2] = d.color.blue;
+        rm.alpha = d.alpha;
+        rm.ior = d.ior;
         putName(rm.name, m->name());
         out.materials.push_back(rm);
     }

@@ -19,10 +19,40 @@ void check(int32_t code)
 }
 }  // namespace
 
+BSDFSample Material::sample(const Vector& incident, const Vector& normal, RandomGenerator& generator) const
+{
+    double u1 = 0.0, u2 = 0.0;
+    switch (deviceDescription().bsdf)
+    {
+        case RT_MATERIAL_LAMBERTIAN:
+            u1 = generator.value();
+            u2 = generator.value();
+            break;
+        case RT_MATERIAL_DIELECTRIC:
+            u1 = generator.value();
+            break;
+        case RT_MATERIAL_MICROFACET:
+        {
+            // no draw for light that arrives from behind (reference src/MicrofacetMaterial.cpp:144-153)
+            const double cosThetaI = (0.0 - incident.x) * normal.x + (0.0 - incident.y) * normal.y + (0.0 - incident.z) * normal.z;
+            if (cosThetaI > 0.0)
+            {
+                u1 = generator.value();
+                u2 = generator.value();
+            }
+            break;
+        }
+        default:
+            break;  // a mirror draws nothing
+    }
+    return sample(incident, normal, u1, u2);
+}
+
 BSDFSample Material::sample(const Vector& incident, const Vector& normal, double u1, double u2) const
 {
-    const double row[14] = {static_cast<double>(static_cast<int>(m_kind)), m_color.red, m_color.green, m_color.blue,
-                            m_alpha, m_ior, incident.x, incident.y, incident.z, normal.x, normal.y, normal.z, u1, u2};
+    const DeviceMaterial d = deviceDescription();
+    const double row[14] = {static_cast<double>(d.bsdf), d.color.red, d.color.green, d.color.blue,
+                            d.alpha, d.ior, incident.x, incident.y, incident.z, normal.x, normal.y, normal.z, u1, u2};
     double out[10] = {};
     check(rt_bsdf_sample(0, 1, row, out));
     BSDFSample s;
@@ -36,8 +66,9 @@ BSDFSample Material::sample(const Vector& incident, const Vector& normal, double
 
 Color Material::evaluate(const Vector& wi, const Vector& wo, const Vector& normal) const
 {
-    const double row[14] = {static_cast<double>(static_cast<int>(m_kind)), m_color.red, m_color.green, m_color.blue,
-                            m_alpha, wi.x, wi.y, wi.z, wo.x, wo.y, wo.z, normal.x, normal.y, normal.z};
+    const DeviceMaterial d = deviceDescription();
+    const double row[14] = {static_cast<double>(d.bsdf), d.color.red, d.color.green, d.color.blue,
+                            d.alpha, wi.x, wi.y, wi.z, wo.x, wo.y, wo.z, normal.x, normal.y, normal.z};
     double out[4] = {};
     check(rt_bsdf_evaluate(0, 1, row, out));
     return Color{static_cast<float>(out[0]), static_cast<float>(out[1]), static_cast<float>(out[2])};
@@ -45,8 +76,9 @@ Color Material::evaluate(const Vector& wi, const Vector& wo, const Vector& norma
 
 double Material::pdf(const Vector& wi, const Vector& wo, const Vector& normal) const
 {
-    const double row[14] = {static_cast<double>(static_cast<int>(m_kind)), m_color.red, m_color.green, m_color.blue,
-                            m_alpha, wi.x, wi.y, wi.z, wo.x, wo.y, wo.z, normal.x, normal.y, normal.z};
+    const DeviceMaterial d = deviceDescription();
+    const double row[14] = {static_cast<double>(d.bsdf), d.color.red, d.color.green, d.color.blue,
+                            d.alpha, wi.x, wi.y, wi.z, wo.x, wo.y, wo.z, normal.x, normal.y, normal.z};
     double out[4] = {};
     check(rt_bsdf_evaluate(0, 1, row, out));
     return out[3];

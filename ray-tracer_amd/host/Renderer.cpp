@@ -185,28 +185,54 @@ RenderResult renderFrame(const LoadedScene& scene, ProgressCallback progress, Pr
     }
 
     // ---- the photon pass (replaces the Worker threads, reference src/Renderer.cpp:421-582) ----
-    rt_trace_params params{};
-    params.sink_mode = settings.useProbeGather ? RT_SINK_PROBE : RT_SINK_SPLAT;
-    params.first_photon = 0;
-    params.photon_count = settings.photonsPerLight;
-    check(rt_trace(tracer.ptr, &params));
+    // Without a progress callback the whole budget is one pass.  With one, the budget goes out in up
+    // to eight index ranges (the sinks add up over ranges) and the callback is asked between them, so
+    // that returning false stops the frame early as it does in the reference's poll loop — a range
+    // that has been launched runs to its end.
+    const size_t perLight = settings.photonsPerLight;
+    const size_t totalWork = perLight * static_cast<size_t>(flat.scene.light_count);
+    const size_t pieces = progress ? std::max<size_t>(1, std::min<size_t>(8, perLight / 1000000)) : 1;
+    size_t traced = 0;
+    bool goOn = true;
+    for (size_t piece = 0; piece < pieces && goOn && perLight > 0; ++piece)
     {
-        // the reference polls its queues every 250 ms from the calling thread; here the
-        // wait for the stream runs on a helper thread and the callbacks keep firing
-        std::future<int32_t> done = std::async(std::launch::async, [&]() { return rt_synchronize(tracer.ptr); });
-        const size_t totalWork = settings.photonsPerLight * static_cast<size_t>(flat.scene.light_count);
+        rt_trace_params params{};
+        params.sink_mode = settings.useProbeGather ? RT_SINK_PROBE : RT_SINK_SPLAT;
+        params.first_photon = perLight * piece / pieces;
+        params.photon_count = perLight * (piece + 1) / pieces - params.first_photon;
+        if (params.photon_count == 0)
+        {
+            continue;
+        }
+        check(rt_trace(tracer.ptr, &params));
+        // the reference polls its queues every 250 ms from the calling thread; here the wait for the
+        // stream runs on a helper thread and the callbacks keep firing.  The library keeps its error
+        // text per thread, so the helper hands it back together with the code.
+        std::future<std::pair<int32_t, std::string>> done = std::async(std::launch::async, [&]() {
+            const int32_t code = rt_synchronize(tracer.ptr);
+            return std::make_pair(code, code == RT_OK ? std::string() : std::string(rt_last_error()));
+        });
         while (done.wait_for(std::chrono::milliseconds(250)) != std::future_status::ready)
         {
-            if (progress && !progress(totalWork))
+            if (progress && !progress(totalWork - traced))
             {
-                break;  // the pass cannot be interrupted on the device; the partial-abort contract is "finish"
+                goOn = false;  // takes effect once this range has finished
             }
         }
-        check(done.get());
-        if (progress)
+        const std::pair<int32_t, std::string> waited = done.get();
+        if (waited.first != RT_OK)
         {
-            progress(0);
+            throw std::runtime_error("rt_amd: " + waited.second);
         }
+        traced += static_cast<size_t>(params.photon_count) * static_cast<size_t>(flat.scene.light_count);
+        if (progress && goOn && piece + 1 < pieces)
+        {
+            goOn = progress(totalWork - traced);
+        }
+    }
+    if (progress)
+    {
+        progress(0);
     }
     rt_counters counters{};
     check(rt_read_counters(tracer.ptr, &counters));

@@ -14,6 +14,7 @@
 #include <filesystem>
 #include <limits>
 #include <map>
+#include <random>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -222,9 +223,29 @@ public:
 };
 
 // ------------------------------------------------------------------ materials
-// The BSDF interface of reference include/Material.h:34-128.  sample()/evaluate()
-// run the device implementation through the C-ABI (one-element batches) — there is
-// no host BSDF code to fall back to.
+// reference include/RandomGenerator.h:6-22, src/RandomGenerator.cpp:3-17: the sequential draw source
+// of the reference's host-side interfaces (the photon pass itself draws from per-photon counter streams).
+class RandomGenerator
+{
+public:
+    RandomGenerator() : m_generator(std::random_device{}()) {}
+    explicit RandomGenerator(std::uint32_t seed) : m_generator(seed) {}
+    double value(double scale = 1.0) { return m_distribution(m_generator) * scale; }
+
+private:
+    std::mt19937 m_generator;
+    std::uniform_real_distribution<double> m_distribution{0.0, 1.0};
+};
+
+// The BSDF interface of reference include/Material.h:34-128: the virtuals a scene's materials are
+// used through.  The photon pass runs on the device, so a material is, to the pass, the record
+// deviceDescription() returns: the id of a device BSDF (RT_MATERIAL_* of include/rt_scene.h) and its
+// parameters.  The host-side sample / evaluate / pdf evaluate that same record with the device
+// library's function-level entry points (rt_bsdf_sample, rt_bsdf_evaluate: one-element batches), so
+// that the interface and the pass share ONE implementation of every BSDF and there is no host BSDF
+// code to fall out of step.  A new material that is a re-parameterisation of an existing BSDF
+// overrides deviceDescription() only; a new BSDF takes a new id and its three device functions
+// (sampleMaterial / evaluateMaterial / pdfMaterial in csrc/rt_device.h) as well.
 struct BSDFSample
 {
     Vector direction;
@@ -232,6 +253,14 @@ struct BSDFSample
     double pdf = 0.0;
     bool isDelta = false;
     bool valid = false;
+};
+
+struct DeviceMaterial
+{
+    int bsdf = 0;        // RT_MATERIAL_LAMBERTIAN / _MIRROR / _DIELECTRIC / _MICROFACET
+    Color color{1.0f};   // albedo or tint
+    double alpha = 0.3;  // GGX roughness (microfacet)
+    double ior = 1.5;    // index of refraction (dielectric)
 };
 
 class Material
@@ -255,13 +284,34 @@ public:
     const Color& color() const { return m_color; }
     double alpha() const { return m_alpha; }
     double ior() const { return m_ior; }
-    virtual bool isDelta() const { return m_kind == Kind::Mirror || m_kind == Kind::Dielectric; }
 
-    // u1/u2 are the uniform draws the sample consumes (Lambertian, Microfacet: both;
-    // Dielectric: u1; Mirror: none).
+    // What the device runs for this material (Flatten.cpp copies it into rt_material).
+    virtual DeviceMaterial deviceDescription() const
+    {
+        return DeviceMaterial{static_cast<int>(m_kind), m_color, m_alpha, m_ior};
+    }
+
+    // reference include/Material.h:56-101.  sample() draws from `generator` what the BSDF consumes,
+    // in the reference's order: Lambertian two draws, Mirror none, Dielectric one, Microfacet two
+    // once the incident direction is known to arrive from the front (src/LambertianMaterial.cpp:57-58,
+    // src/DielectricMaterial.cpp:118, src/MicrofacetMaterial.cpp:149-163).
+    virtual BSDFSample sample(const Vector& incident, const Vector& normal, RandomGenerator& generator) const;
+    virtual BSDFSample sampleMode(const Vector& incident, const Vector& normal, RandomGenerator& generator) const
+    {
+        return sample(incident, normal, generator);
+    }
+    virtual Color evaluate(const Vector& wi, const Vector& wo, const Vector& normal) const;
+    virtual double pdf(const Vector& wi, const Vector& wo, const Vector& normal) const;
+    virtual bool isDelta() const
+    {
+        const int bsdf = deviceDescription().bsdf;
+        return bsdf == static_cast<int>(Kind::Mirror) || bsdf == static_cast<int>(Kind::Dielectric);
+    }
+    // one daughter per bounce: the live path of the reference (src/Worker.cpp:655-669)
+    virtual size_t daughterPhotonCount() const { return 1; }
+
+    // The same sample from explicit draws (u1, u2 as far as the BSDF consumes them).
     BSDFSample sample(const Vector& incident, const Vector& normal, double u1, double u2) const;
-    Color evaluate(const Vector& wi, const Vector& wo, const Vector& normal) const;
-    double pdf(const Vector& wi, const Vector& wo, const Vector& normal) const;
 
 private:
     std::string m_name;

@@ -69,6 +69,60 @@ int rth_frame_derive(const rt_scene* scene, double out[4])
     return 0;
 }
 
+int rth_material_sample(const rth_scene* scene, int32_t material, const double in6[6], uint32_t seed, double out9[9])
+{
+    try
+    {
+        const std::shared_ptr<Material> m = scene->loaded.materialLibrary->fetchByIndex(static_cast<size_t>(material));
+        RandomGenerator generator(seed), replay(seed);
+        const BSDFSample sample = m->sample(Vector{in6[0], in6[1], in6[2]}, Vector{in6[3], in6[4], in6[5]}, generator);
+        out9[0] = sample.valid ? 1.0 : 0.0;
+        out9[1] = sample.direction.x;
+        out9[2] = sample.direction.y;
+        out9[3] = sample.direction.z;
+        out9[4] = sample.weight.red;
+        out9[5] = sample.weight.green;
+        out9[6] = sample.weight.blue;
+        out9[7] = sample.pdf;
+        // draws consumed: the first value the two generators disagree on
+        // draws consumed: how far a generator of the same seed has to run to meet this one's next value
+        int draws = 0;
+        const double next = generator.value();
+        for (; draws < 8; ++draws)
+        {
+            if (replay.value() == next) break;
+        }
+        out9[8] = static_cast<double>(draws);
+        return 0;
+    }
+    catch (const std::exception& e)
+    {
+        g_error = e.what();
+        return 1;
+    }
+}
+
+int rth_material_evaluate(const rth_scene* scene, int32_t material, const double in9[9], double out5[5])
+{
+    try
+    {
+        const std::shared_ptr<Material> m = scene->loaded.materialLibrary->fetchByIndex(static_cast<size_t>(material));
+        const Vector wi{in9[0], in9[1], in9[2]}, wo{in9[3], in9[4], in9[5]}, normal{in9[6], in9[7], in9[8]};
+        const Color f = m->evaluate(wi, wo, normal);
+        out5[0] = f.red;
+        out5[1] = f.green;
+        out5[2] = f.blue;
+        out5[3] = m->pdf(wi, wo, normal);
+        out5[4] = m->isDelta() ? 1.0 : 0.0;
+        return 0;
+    }
+    catch (const std::exception& e)
+    {
+        g_error = e.what();
+        return 1;
+    }
+}
+
 int rth_write_png16(const char* path, const uint16_t* rgb, int32_t width, int32_t height, const char* title)
 {
     if (path == nullptr || rgb == nullptr || width <= 0 || height <= 0)

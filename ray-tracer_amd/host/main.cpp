@@ -1,6 +1,9 @@
-// ray-tracer <scene.json>: the reference's command line (src/main.cpp:22-154).  Loads the
-// scene, renders frames startFrame..endFrame on GPU 0, writes <renderPath>/<renderName>.<frame>.png
-// (and one PNG per additional camera that names an output), exits 1 on any error.
+// ray-tracer <scene.json> — the command line of the reference (src/main.cpp:22-154) in front of
+// the device renderer.  What a caller can observe is kept: the greeting and farewell lines, the
+// usage messages, "ERROR: ..." with exit status 1 for anything that throws, one
+// <renderPath>/<renderName>.<frame>.png per frame (plus one per further camera that names an
+// output), and the per-frame report lines.  The structure is this program's own: a small
+// command-line front (usage checks), a frame schedule, and one report object per frame.
 #include "PngWriter.h"
 #include "Renderer.h"
 #include "SceneLoader.h"
@@ -11,134 +14,189 @@
 #include <filesystem>
 #include <fstream>
 #include <iostream>
+#include <optional>
+#include <string>
+#include <vector>
 
 namespace
 {
 
-// Optional raw dump of the float buffers (RT_DUMP_BUFFERS=<dir>): camera<c>.f32 holds
-// height x width x 3 floats; used to compare frames without the 16-bit quantisation.
-void dumpBuffers(const RenderResult& render, const std::filesystem::path& dir)
+namespace fs = std::filesystem;
+using Clock = std::chrono::steady_clock;
+
+void say(const std::string& line) { std::cout << line << std::endl; }
+
+// The project file named on the command line, or nothing after the matching usage message.
+std::optional<fs::path> projectFileFrom(const std::vector<std::string>& arguments)
 {
-    std::filesystem::create_directories(dir);
-    for (size_t c = 0; c < render.cameras.size(); ++c)
+    if (arguments.empty())
     {
-        const Buffer& buffer = *render.cameras[c].buffer;
-        std::ofstream out(dir / ("camera" + std::to_string(c) + ".f32"), std::ios::binary);
+        say("Please provide a project file to process");
+        return std::nullopt;
+    }
+    if (arguments.size() != 1)
+    {
+        say("Too many arguments, only 1 required");
+        return std::nullopt;
+    }
+    const fs::path candidate = arguments.front();
+    if (!fs::is_regular_file(candidate))
+    {
+        std::cout << "Provided path is invalid: " << candidate << std::endl;
+        return std::nullopt;
+    }
+    return candidate;
+}
+
+// The instant a frame's shutter opens: frameOffset + frame / frameRate (24 frames a second when
+// the scene names no rate).  This is the one place a frame number becomes a scene time.
+double shutterOpens(const RenderSettings& settings, size_t frame)
+{
+    const double perSecond = settings.frameRate > 0.0 ? settings.frameRate : 24.0;
+    return settings.frameOffset + static_cast<double>(frame) / perSecond;
+}
+
+// Raw float buffers next to the PNGs (RT_DUMP_BUFFERS=<dir>): camera<c>.f32 holds
+// height x width x 3 floats, for comparisons that the 16-bit quantisation would blur.
+void dumpBuffers(const RenderResult& render, const fs::path& directory)
+{
+    fs::create_directories(directory);
+    size_t index = 0;
+    for (const CameraRender& camera : render.cameras)
+    {
+        const Buffer& buffer = *camera.buffer;
+        std::ofstream out(directory / ("camera" + std::to_string(index++) + ".f32"), std::ios::binary);
         out.write(reinterpret_cast<const char*>(buffer.data()),
                   static_cast<std::streamsize>(buffer.width() * buffer.height() * 3 * sizeof(float)));
     }
+}
+
+void writePng(const fs::path& path, const Image& image, const std::string& title)
+{
+    if (!PngWriter::writeImage(path, image, title))
+    {
+        throw std::runtime_error("cannot write " + path.generic_string());
+    }
+    say("Wrote " + path.generic_string());
+}
+
+// Everything printed about one finished frame.
+struct FrameReport
+{
+    const LoadedScene& scene;
+    const RenderResult& render;
+
+    void photonPass() const
+    {
+        std::cout << "Photon pass: photons=" << render.photons << " casts=" << render.casts << " bounces=" << render.bounces
+                  << " seconds=" << render.photonPassSeconds << std::endl;
+    }
+
+    void probeGather() const
+    {
+        if (!scene.settings.useProbeGather)
+        {
+            return;
+        }
+        const size_t tested = render.bounceKept + render.bounceCulled;
+        const double culledShare = tested == 0 ? 0.0 : 100.0 * static_cast<double>(render.bounceCulled) / static_cast<double>(tested);
+        const bool overflowed = render.bounceStoreDropped > 0;
+        std::cout << "Probe gather: kept=" << render.bounceKept << " culled=" << render.bounceCulled << " (" << culledShare
+                  << "% culled) storeSize=" << render.bounceStoreSize
+                  << " storeMiB=" << (render.bounceStoreCapacity * 52 / (1024 * 1024)) << (overflowed ? " [BUDGET HIT]" : "")
+                  << std::endl;
+        if (overflowed)
+        {
+            std::cout << "Probe gather: DROPPED " << render.bounceStoreDropped
+                      << " deposits (BounceStore overflow — image is missing energy; raise $bounceStoreCapacity)" << std::endl;
+        }
+    }
+
+    void timing(std::chrono::microseconds spent) const
+    {
+        say("Render time:");
+        std::cout << "|- total:        " << spent.count() / 1000 << " ms" << std::endl;
+        const size_t pixels = scene.settings.imageWidth * scene.settings.imageHeight;
+        if (pixels > 0)
+        {
+            std::cout << "|- average / px: " << spent.count() / pixels << " us" << std::endl;
+        }
+    }
+};
+
+void renderOneFrame(LoadedScene& scene, size_t frame, size_t ordinal, size_t frameTotal)
+{
+    say("---");
+    std::cout << "Rendering frame " << ordinal << " / " << frameTotal << std::endl;
+    const Clock::time_point started = Clock::now();
+    scene.settings.frameTime = shutterOpens(scene.settings, frame);
+    std::cout << "Frame time t=" << scene.settings.frameTime << "s shutter=" << scene.settings.shutterTime << "s" << std::endl;
+
+    const RenderResult render = Renderer::renderFrame(scene);
+    const auto spent = std::chrono::duration_cast<std::chrono::microseconds>(Clock::now() - started);
+
+    const FrameReport report{scene, render};
+    report.photonPass();
+    report.probeGather();
+
+    const std::string suffix = "." + std::to_string(frame) + ".png";
+    const Clock::time_point writing = Clock::now();
+    writePng(scene.renderPath / (scene.renderName + suffix), *render.image, scene.renderName);
+    if (std::getenv("RT_AMD_VERBOSE"))
+    {
+        std::fprintf(stderr, "[rt_amd] %-28s %8.1f ms\n", "PNG written",
+                     std::chrono::duration<double, std::milli>(Clock::now() - writing).count());
+    }
+    for (size_t c = 1; c < render.cameras.size(); ++c)
+    {
+        const CameraRender& extra = render.cameras[c];
+        if (!extra.outputName.empty() && extra.image)
+        {
+            writePng(scene.renderPath / (extra.outputName + suffix), *extra.image, extra.outputName);
+        }
+    }
+    if (const char* directory = std::getenv("RT_DUMP_BUFFERS"))
+    {
+        dumpBuffers(render, directory);
+    }
+    report.timing(spent);
+}
+
+int renderProject(const fs::path& projectFile)
+{
+    LoadedScene scene = SceneLoader::loadFromFile(projectFile, /*logToStdout=*/true);
+    const size_t first = scene.settings.startFrame, last = scene.settings.endFrame;
+    say("---");
+    std::cout << "Rendering image at " << scene.settings.imageWidth << " px by " << scene.settings.imageHeight << " px"
+              << std::endl;
+    const size_t frameTotal = last - first + 1;
+    for (size_t frame = first; frame <= last; ++frame)
+    {
+        renderOneFrame(scene, frame, frame + 1, frameTotal);
+    }
+    return 0;
 }
 
 }  // namespace
 
 int main(int argc, char** argv)
 {
-    std::cout << "Hello!" << std::endl;
-    if (argc == 1)
+    say("Hello!");
+    const std::optional<fs::path> projectFile = projectFileFrom(std::vector<std::string>(argv + (argc > 0 ? 1 : 0), argv + argc));
+    if (!projectFile)
     {
-        std::cout << "Please provide a project file to process" << std::endl;
-        return 1;
-    }
-    else if (argc > 2)
-    {
-        std::cout << "Too many arguments, only 1 required" << std::endl;
-        return 1;
-    }
-    const std::filesystem::path projectFilePath = argv[1];
-    if (!std::filesystem::is_regular_file(projectFilePath))
-    {
-        std::cout << "Provided path is invalid: " << projectFilePath << std::endl;
         return 1;
     }
     try
     {
-        LoadedScene scene = SceneLoader::loadFromFile(projectFilePath, /*logToStdout=*/true);
-        const size_t startFrame = scene.settings.startFrame;
-        const size_t endFrame = scene.settings.endFrame;
-        const size_t frameCount = (endFrame - startFrame) + 1;
-        const size_t pixelCount = scene.settings.imageWidth * scene.settings.imageHeight;
-        std::cout << "---" << std::endl;
-        std::cout << "Rendering image at " << scene.settings.imageWidth << " px by " << scene.settings.imageHeight
-                  << " px" << std::endl;
-        for (size_t frame = startFrame; frame <= endFrame; ++frame)
-        {
-            std::cout << "---" << std::endl;
-            std::cout << "Rendering frame " << frame + 1 << " / " << frameCount << std::endl;
-            const auto renderStart = std::chrono::steady_clock::now();
-            const double frameRate = (scene.settings.frameRate > 0.0) ? scene.settings.frameRate : 24.0;
-            scene.settings.frameTime = scene.settings.frameOffset + static_cast<double>(frame) / frameRate;
-            std::cout << "Frame time t=" << scene.settings.frameTime << "s"
-                      << " shutter=" << scene.settings.shutterTime << "s" << std::endl;
-
-            const RenderResult render = Renderer::renderFrame(scene);
-
-            const auto renderDuration = std::chrono::duration_cast<std::chrono::microseconds>(
-                std::chrono::steady_clock::now() - renderStart);
-            std::cout << "Photon pass: photons=" << render.photons << " casts=" << render.casts
-                      << " bounces=" << render.bounces << " seconds=" << render.photonPassSeconds << std::endl;
-            if (scene.settings.useProbeGather)
-            {
-                const size_t total = render.bounceKept + render.bounceCulled;
-                const double cullPct =
-                    total > 0 ? 100.0 * static_cast<double>(render.bounceCulled) / static_cast<double>(total) : 0.0;
-                std::cout << "Probe gather: kept=" << render.bounceKept << " culled=" << render.bounceCulled << " ("
-                          << cullPct << "% culled)"
-                          << " storeSize=" << render.bounceStoreSize
-                          << " storeMiB=" << (render.bounceStoreCapacity * 52 / (1024 * 1024))
-                          << (render.bounceStoreDropped > 0 ? " [BUDGET HIT]" : "") << std::endl;
-                if (render.bounceStoreDropped > 0)
-                {
-                    std::cout << "Probe gather: DROPPED " << render.bounceStoreDropped
-                              << " deposits (BounceStore overflow — image is missing energy; raise "
-                                 "$bounceStoreCapacity)"
-                              << std::endl;
-                }
-            }
-            const std::string fileName = scene.renderName + "." + std::to_string(frame) + ".png";
-            const std::filesystem::path outputPath = scene.renderPath / fileName;
-            const auto writeStart = std::chrono::steady_clock::now();
-            if (!PngWriter::writeImage(outputPath, *render.image, scene.renderName))
-            {
-                throw std::runtime_error("cannot write " + outputPath.generic_string());
-            }
-            std::cout << "Wrote " << outputPath.generic_string() << std::endl;
-            if (std::getenv("RT_AMD_VERBOSE"))
-            {
-                std::fprintf(stderr, "[rt_amd] %-28s %8.1f ms\n", "PNG written",
-                             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - writeStart).count());
-            }
-            for (size_t c = 1; c < render.cameras.size(); ++c)
-            {
-                const CameraRender& cr = render.cameras[c];
-                if (cr.outputName.empty() || !cr.image)
-                {
-                    continue;
-                }
-                const std::filesystem::path extra =
-                    scene.renderPath / (cr.outputName + "." + std::to_string(frame) + ".png");
-                if (!PngWriter::writeImage(extra, *cr.image, cr.outputName))
-                {
-                    throw std::runtime_error("cannot write " + extra.generic_string());
-                }
-                std::cout << "Wrote " << extra.generic_string() << std::endl;
-            }
-            if (const char* dump = std::getenv("RT_DUMP_BUFFERS"))
-            {
-                dumpBuffers(render, dump);
-            }
-            std::cout << "Render time:" << std::endl;
-            std::cout << "|- total:        " << renderDuration.count() / 1000 << " ms" << std::endl;
-            if (pixelCount > 0)
-            {
-                std::cout << "|- average / px: " << renderDuration.count() / pixelCount << " us" << std::endl;
-            }
-        }
+        renderProject(*projectFile);
     }
-    catch (const std::exception& e)
+    catch (const std::exception& failure)
     {
-        std::cout << "ERROR: " << e.what() << std::endl;
+        // a failed render has to fail the process: scripts and CI gates read the exit status
+        say(std::string("ERROR: ") + failure.what());
         return 1;
     }
-    std::cout << "Goodbye!" << std::endl;
+    say("Goodbye!");
     return 0;
 }
