@@ -245,7 +245,11 @@ struct rt_tracer
         DeviceArray<uint32_t> orderIn, orderOut;
         DeviceArray<unsigned char> scratch;
         DeviceArray<float> sortedStore;
+        // the index these arrays hold: valid while the store has not changed since (storeVersion)
+        uint64_t indexedVersion = 0, indexedRecords = 0, indexed = 0;
+        double indexedCellSize = 0.0;
     } gatherSpace;
+    uint64_t storeVersion = 1;  // bumped by everything that writes the store or its cursor
 
     rtd::SceneView view{};
     int computeUnits = 0;
@@ -1345,6 +1349,7 @@ void setProbes(rt_tracer* tracer, const double* probes, bool probesOnDevice, uin
     const double invCellSize = 1.0 / cellSize;
     const double keepRadius = keep_radius > 0.0 ? keep_radius : 0.0;
     tracer->storeCapacity = store_capacity;
+    tracer->storeVersion += 1;
     tracer->storeRecords.allocate(static_cast<size_t>(store_capacity) * 13);
     // the usual case (one cell of reach, coordinates that pack) is built on the device
     if (buildProbesOnDevice(tracer, probes, probesOnDevice, n, invCellSize, keepRadius))
@@ -1474,6 +1479,7 @@ int32_t rt_deposit_emitters(rt_tracer* tracer, double deposit_spacing, uint64_t*
 {
     return guarded([&]() {
         require(tracer != nullptr, "tracer is null");
+        tracer->storeVersion += 1;
         if (!tracer->probesSet)
         {
             throw ApiError(RT_ERR_STATE, "rt_deposit_emitters needs the probes (rt_set_probes) first");
@@ -1601,6 +1607,7 @@ int32_t rt_reset(rt_tracer* tracer)
 {
     return guarded([&]() {
         require(tracer != nullptr, "tracer is null");
+        tracer->storeVersion += 1;
         activate(tracer);
         resetState(tracer);
     });
@@ -1690,6 +1697,7 @@ int32_t rt_trace(rt_tracer* tracer, const rt_trace_params* params)
     return guarded([&]() {
         require(tracer != nullptr && params != nullptr, "null argument");
         activate(tracer);
+        tracer->storeVersion += 1;
         uint64_t first = 0, count = 0;
         resolveRange(tracer, params, &first, &count);
         requireSink(tracer, params);
@@ -1847,6 +1855,7 @@ int32_t rt_trace_static(rt_tracer* tracer, const rt_trace_params* params)
     return guarded([&]() {
         require(tracer != nullptr && params != nullptr, "null argument");
         activate(tracer);
+        tracer->storeVersion += 1;
         uint64_t first = 0, count = 0;
         resolveRange(tracer, params, &first, &count);
         requireSink(tracer, params);
@@ -2100,6 +2109,7 @@ int32_t rt_store_append(rt_tracer* tracer, const float* records13, uint64_t n)
 {
     return guarded([&]() {
         require(tracer != nullptr, "tracer is null");
+        tracer->storeVersion += 1;
         require(n == 0 || records13 != nullptr, "records is null");
         if (!tracer->probesSet)
         {
@@ -2159,7 +2169,12 @@ int32_t rt_gather(rt_tracer* tracer, int32_t camera, double gather_cell_size, do
         auto& stats = g.stats;
         if (stats.count == 0) stats.allocate(4);  // [0..1] the launch's tallies, [2] records that carry a key
         uint64_t indexed = 0;
-        if (n > 0)
+        const bool reuse = g.indexedVersion == tracer->storeVersion && g.indexedRecords == n && g.indexedCellSize == cellSize;
+        if (reuse)
+        {
+            indexed = g.indexed;  // another camera of the same frame has built this index already
+        }
+        else if (n > 0)
         {
             if (keysIn.count < n)
             {
@@ -2192,6 +2207,10 @@ int32_t rt_gather(rt_tracer* tracer, int32_t camera, double gather_cell_size, do
                 check(hipGetLastError(), "store reorder launch");
             }
         }
+        g.indexedVersion = tracer->storeVersion;
+        g.indexedRecords = n;
+        g.indexedCellSize = cellSize;
+        g.indexed = indexed;
         check(hipMemsetAsync(stats.ptr, 0, 2 * sizeof(unsigned long long), tracer->stream), "hipMemsetAsync gather stats");
 
         rtd::GatherArgs args{};

@@ -33,6 +33,18 @@ RT_DEV unsigned lanesBelow(unsigned long long mask)
                                      __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(mask), 0u));
 }
 
+// The value `v` holds in lane `lane` of the wave (the same lane for every caller: a scalar read, not a
+// trip through the LDS crossbar).
+RT_DEV float laneValue(float v, int lane)
+{
+    return __uint_as_float(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(__float_as_uint(v)), lane)));
+}
+
+RT_DEV uint32_t laneValue(uint32_t v, int lane)
+{
+    return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), lane));
+}
+
 RT_DEV unsigned long long waveSum(unsigned long long v)
 {
 #pragma unroll
@@ -408,7 +420,7 @@ RT_DEV void addToPixels(float* buffer, bool emit, uint32_t index, const Color& c
     for (int round = 0; pending != 0; ++round)
     {
         const int leader = __builtin_ctzll(pending);
-        const uint32_t pixel = __shfl(index, leader, 64);
+        const uint32_t pixel = laneValue(index, leader);
         const bool same = emit && index == pixel;
         unsigned long long members = __ballot(same);
         const bool lastRound = round == kRounds - 1;
@@ -431,9 +443,9 @@ RT_DEV void addToPixels(float* buffer, bool emit, uint32_t index, const Color& c
         {
             const int k = __builtin_ctzll(members);
             members &= members - 1;
-            r += __shfl(contribution.r, k, 64);
-            g += __shfl(contribution.g, k, 64);
-            b += __shfl(contribution.b, k, 64);
+            r += laneValue(contribution.r, k);
+            g += laneValue(contribution.g, k);
+            b += laneValue(contribution.b, k);
         }
         if (static_cast<int>(threadIdx.x & 63) == leader)
         {
@@ -1505,13 +1517,30 @@ RT_DEV Color gatherRadianceGroup(const GatherArgs& a, const GatherPoint& gp, int
     Color sum = black;
     unsigned long long kept = 0;
     const bool bySlab = (y1 - y0) > 16;  // as in gatherRadiance
-    for (int64_t z = z0; z <= z1; ++z)
+    // The rows of cells are walked in the order of gatherRadiance (z outside, y inside), but where each
+    // row starts in the key list is looked up G rows at a time, one row per lane of the group: the
+    // binary searches, chains of dependent reads, run side by side instead of one after the other.
+    const int64_t rowsPerSlab = bySlab ? 1 : (y1 - y0 + 1);
+    const int64_t rowCount = (z1 - z0 + 1) * rowsPerSlab;
+    for (int64_t rowBase = 0; rowBase < rowCount; rowBase += G)
     {
-        for (int64_t y = y0; y <= y1; ++y)
+        uint64_t myStart = 0;
+        if (rowBase + member < rowCount)
         {
-            const unsigned long long first = packCell(x0, y, z);
+            const int64_t mine = rowBase + member;
+            myStart = lowerBound(a.keys, a.indexed, packCell(x0, y0 + mine % rowsPerSlab, z0 + mine / rowsPerSlab));
+        }
+        const int rowsHere = static_cast<int>(rowCount - rowBase < G ? rowCount - rowBase : G);
+        for (int t = 0; t < rowsHere; ++t)
+        {
+            const int64_t row = rowBase + t;
+            const int64_t y = y0 + row % rowsPerSlab, z = z0 + row / rowsPerSlab;
             const unsigned long long last = bySlab ? packCell(x1, y1, z) : packCell(x1, y, z);
-            for (uint64_t base = lowerBound(a.keys, a.indexed, first);; base += G)
+            const uint32_t startLo = G == 64 ? laneValue(static_cast<uint32_t>(myStart), t)
+                                             : __shfl(static_cast<uint32_t>(myStart), t, G);
+            const uint32_t startHi = G == 64 ? laneValue(static_cast<uint32_t>(myStart >> 32), t)
+                                             : __shfl(static_cast<uint32_t>(myStart >> 32), t, G);
+            for (uint64_t base = (static_cast<uint64_t>(startHi) << 32) | startLo;; base += G)
             {
                 typedef float Float4At4 __attribute__((ext_vector_type(4), aligned(4)));
                 const uint64_t j = base + static_cast<uint64_t>(member);
@@ -1584,9 +1613,9 @@ RT_DEV Color gatherRadianceGroup(const GatherArgs& a, const GatherPoint& gp, int
                     {
                         const int k = __builtin_ctzll(todo);
                         todo &= todo - 1;
-                        sum.r += __shfl(contribution.r, k, 64);
-                        sum.g += __shfl(contribution.g, k, 64);
-                        sum.b += __shfl(contribution.b, k, 64);
+                        sum.r += laneValue(contribution.r, k);
+                        sum.g += laneValue(contribution.g, k);
+                        sum.b += laneValue(contribution.b, k);
                     }
                     if (beyondMask != 0) break;
                 }
@@ -1604,10 +1633,6 @@ RT_DEV Color gatherRadianceGroup(const GatherArgs& a, const GatherPoint& gp, int
                     }
                     if (groupBits<G>(beyondMask, groupBase) != 0) break;
                 }
-            }
-            if (bySlab)
-            {
-                break;  // the slab scan covered every row of this z
             }
         }
     }
