@@ -210,6 +210,10 @@ struct rt_tracer
     // emission-order list of a pass's photon ids
     DeviceArray<uint32_t> sortIds, sortOrder, sortKeysIn, sortKeysOut;
     DeviceArray<rtd::PhotonState> photonQueue[2];
+    // keys of the parked photons' rays, their sorted copy, the slot numbers in key order, 0..n-1
+    DeviceArray<uint32_t> queueKeys, queueKeysSorted, queueOrder, queueIota;
+    float keyOrigin[3] = {0.0f, 0.0f, 0.0f};
+    float keyScale = 1.0f;
 
     DeviceArray<unsigned long long> queueCounts;
     DeviceArray<unsigned char> sortScratch;
@@ -756,6 +760,36 @@ void buildScene(rt_tracer* t, const rt_scene* scene)
     t->animations.upload(animations);
     t->keyframes.upload(keyframes);
 
+    // box of the ray keys: the world boxes of the static volumes (a volume without one counts as the scene's scale)
+    {
+        float lo[3] = {1e30f, 1e30f, 1e30f}, hi[3] = {-1e30f, -1e30f, -1e30f};
+        bool any = false, open = false;
+        for (const rtd::Volume& v : volumes)
+        {
+            if (!v.hasWorldBox)
+            {
+                open = true;
+                continue;
+            }
+            any = true;
+            for (int k = 0; k < 3; ++k)
+            {
+                lo[k] = std::min(lo[k], v.worldBox[k]);
+                hi[k] = std::max(hi[k], v.worldBox[3 + k]);
+            }
+        }
+        if (!any || open)
+        {
+            for (int k = 0; k < 3; ++k)
+            {
+                lo[k] = any ? std::min(lo[k], -static_cast<float>(sceneScale)) : -static_cast<float>(sceneScale);
+                hi[k] = any ? std::max(hi[k], static_cast<float>(sceneScale)) : static_cast<float>(sceneScale);
+            }
+        }
+        const float side = std::max({hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2], 1e-6f});
+        for (int k = 0; k < 3; ++k) t->keyOrigin[k] = lo[k];
+        t->keyScale = 1.0f / side;
+    }
     t->volumes.upload(volumes);
     t->cacheImage.upload(cacheImage);
     t->nodes.upload(nodes);
@@ -1790,6 +1824,25 @@ int32_t rt_trace(rt_tracer* tracer, const rt_trace_params* params)
             tracer->photonQueue[0].allocate(capacity);
             tracer->photonQueue[1].allocate(capacity);
         }
+        // Parked photons are re-ordered by a key of their ray before the next launch (RT_AMD_LEVEL_SORT=0
+        // turns that off, any other value is the key's layout as rayKey reads it; RT_AMD_LEVEL_SORT_MIN=<photons>
+        // is the smallest level worth a sort).
+        int keyMode = 5 | (7 << 4);  // 32 cells per axis above 7 x 7 sectors per face (measured best on MirrorKnot4k)
+        uint64_t sortMinimum = 1ull << 20;
+        if (const char* v = std::getenv("RT_AMD_LEVEL_SORT")) keyMode = static_cast<int>(std::strtol(v, nullptr, 0));
+        if (const char* v = std::getenv("RT_AMD_LEVEL_SORT_MIN")) sortMinimum = std::strtoull(v, nullptr, 10);
+        const int originBits = keyMode & 15, sectorCells = (keyMode >> 4) & 15;
+        int keyBits = 3 * originBits;
+        while (sectorCells > 0 && (1 << (keyBits - 3 * originBits)) < 6 * sectorCells * sectorCells) ++keyBits;
+        const bool levelSort = levels > 0 && keyMode > 0 && originBits <= 6 && keyBits >= 1 && keyBits <= 32 && capacity < (1ull << 31);
+        if (levelSort && tracer->queueKeys.count < capacity)
+        {
+            tracer->queueKeys.allocate(capacity);
+            tracer->queueKeysSorted.allocate(capacity);
+            tracer->queueOrder.allocate(capacity);
+            tracer->queueIota.allocate(capacity);
+            rtd::launchIota(tracer->queueIota.ptr, capacity, tracer->stream);
+        }
         if (levels > 0 && tracer->queueCounts.count == 0)
         {
             tracer->queueCounts.allocate(static_cast<size_t>(2 * (kQueueLevels + 1)));
@@ -1799,6 +1852,7 @@ int32_t rt_trace(rt_tracer* tracer, const rt_trace_params* params)
             tracer->queueCounts.zero(tracer->stream);
         }
         uint64_t parked = 0;  // photons in the queue the next launch reads
+        bool sortedLevel = false;  // ... in the order of queueOrder
         const bool verbose = std::getenv("RT_AMD_VERBOSE") != nullptr;
         for (int level = 0; level <= levels; ++level)
         {
@@ -1819,8 +1873,20 @@ int32_t rt_trace(rt_tracer* tracer, const rt_trace_params* params)
                 launch.queueOut = tracer->photonQueue[level & 1].ptr;
                 launch.queueOutCount = counts + 2 * level;
                 launch.queueOutCapacity = capacity;
+                if (levelSort)
+                {
+                    launch.queueOutKeys = tracer->queueKeys.ptr;
+                    launch.keyMode = keyMode;
+                    launch.keyScale = tracer->keyScale;
+                    std::memcpy(launch.keyOrigin, tracer->keyOrigin, sizeof(launch.keyOrigin));
+                }
             }
-            const int blocks = scheduleLaunch(launch, work, residentBlocks, level == 0);
+            if (level > 0 && sortedLevel)
+            {
+                launch.queueInOrder = tracer->queueOrder.ptr;
+            }
+            const int blocks = scheduleLaunch(launch, work, residentBlocks, level == 0 || sortedLevel);
+            if (level > 0) launch.claimStride = 1;
             const auto levelStart = std::chrono::steady_clock::now();
             check(rtd::launchTrace(launch, blocks, tracer->stream), "trace launch");
             if (level == levels)
@@ -1841,6 +1907,18 @@ int32_t rt_trace(rt_tracer* tracer, const rt_trace_params* params)
             if (parked == 0)
             {
                 break;
+            }
+            sortedLevel = levelSort && parked >= sortMinimum;
+            if (sortedLevel)
+            {
+                size_t bytes = 0;
+                check(rtd::sortPairs32(nullptr, &bytes, tracer->queueKeys.ptr, tracer->queueKeysSorted.ptr, tracer->queueIota.ptr,
+                                       tracer->queueOrder.ptr, parked, keyBits, tracer->stream),
+                      "sort size query");
+                if (tracer->sortScratch.count < bytes) tracer->sortScratch.allocate(bytes);
+                check(rtd::sortPairs32(tracer->sortScratch.ptr, &bytes, tracer->queueKeys.ptr, tracer->queueKeysSorted.ptr,
+                                       tracer->queueIota.ptr, tracer->queueOrder.ptr, parked, keyBits, tracer->stream),
+                      "parked photon sort");
             }
         }
         check(hipEventRecord(tracer->stageEvents[2], tracer->stream), "hipEventRecord");

@@ -124,6 +124,15 @@ struct TraceArgs
     PhotonState* queueOut;                    // photons that go on after this launch's bounce are parked here
     unsigned long long* queueOutCount;        // slots claimed (may exceed queueOutCapacity)
     uint64_t queueOutCapacity;                // beyond it a photon is followed on in its lane
+    // Parked photons are scattered over the scene in every direction.  Each one leaves a key of its
+    // new ray behind (queueOutKeys[slot]: origin cell, then direction sector); the host sorts the
+    // (key, slot) pairs and the next launch walks the queue through that order (queueInOrder), so
+    // that the 64 photons of a wave start near each other and head the same way.
+    uint32_t* queueOutKeys;                   // optional
+    const uint32_t* queueInOrder;             // optional: position in the launch's work -> slot of queueIn
+    float keyOrigin[3];                       // corner of the scene's box and 1 / (its longest side)
+    float keyScale;
+    int32_t keyMode;                          // how the key is laid out (see rayKey)
 };
 
 hipError_t launchTrace(const TraceArgs& args, int blocks, hipStream_t stream);
@@ -144,6 +153,11 @@ void launchIntersect(int kind, int64_t n, const double* in, void* out, hipStream
 void launchBsdfSample(int64_t n, const double* in14, double* out10, hipStream_t stream);
 void launchBsdfEvaluate(int64_t n, const double* in14, double* out4, hipStream_t stream);
 int traceBlocksPerCu(const TraceArgs& args);
+// values[i] = i
+void launchIota(uint32_t* values, uint64_t n, hipStream_t stream);
+// stable ascending sort of 32-bit (key, value) pairs over the low `bits` bits of the key
+hipError_t sortPairs32(void* scratch, size_t* scratchBytes, const uint32_t* keysIn, uint32_t* keysOut, const uint32_t* valuesIn,
+                       uint32_t* valuesOut, uint64_t n, int bits, hipStream_t stream);
 #ifdef RT_DIAG
 void printDiagnostics();
 #endif

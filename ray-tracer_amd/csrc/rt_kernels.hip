@@ -644,6 +644,56 @@ __global__ void emissionKeysKernel(const TraceArgs a, uint32_t* keys, uint32_t* 
     ids[id] = static_cast<uint32_t>(id);
 }
 
+// Key of a parked photon's ray: the cell of its origin in a grid over the scene's box (Morton order, so
+// that neighbouring keys are neighbouring cells) and the sector of its direction (one of six faces by
+// the dominant axis and its sign, then the two other components relative to it in n x n cells).
+// keyMode packs the layout: bits 0-3 the grid's bits per axis (0: no origin part), bits 4-7 n, bit 8
+// set when the direction sector goes above the origin cell instead of below it.
+RT_DEV uint32_t spreadBits3(uint32_t v)  // bit i of a 6-bit value -> bit 3 * i
+{
+    return (v & 1u) | ((v & 2u) << 2) | ((v & 4u) << 4) | ((v & 8u) << 6) | ((v & 16u) << 8) | ((v & 32u) << 10);
+}
+
+RT_DEV uint32_t rayKey(const TraceArgs& a, const Ray& ray)
+{
+    const int originBits = a.keyMode & 15, sectorCells = (a.keyMode >> 4) & 15;
+    const bool directionAbove = (a.keyMode & 256) != 0;
+    uint32_t morton = 0;
+    if (originBits > 0)
+    {
+        const float cells = static_cast<float>(1 << originBits);
+        uint32_t cell[3];
+        const double o[3] = {ray.o.x, ray.o.y, ray.o.z};
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+        {
+            const float f = (static_cast<float>(o[k]) - a.keyOrigin[k]) * a.keyScale * cells;
+            cell[k] = static_cast<uint32_t>(__builtin_fminf(__builtin_fmaxf(f, 0.0f), cells - 1.0f));
+        }
+        morton = spreadBits3(cell[0]) | (spreadBits3(cell[1]) << 1) | (spreadBits3(cell[2]) << 2);
+    }
+    if (sectorCells == 0)
+    {
+        return morton;
+    }
+    const float d[3] = {static_cast<float>(ray.d.x), static_cast<float>(ray.d.y), static_cast<float>(ray.d.z)};
+    const float ax = __builtin_fabsf(d[0]), ay = __builtin_fabsf(d[1]), az = __builtin_fabsf(d[2]);
+    const int major = (ax >= ay && ax >= az) ? 0 : (ay >= az ? 1 : 2);
+    const float dm = major == 0 ? d[0] : (major == 1 ? d[1] : d[2]);
+    const float du = major == 0 ? d[1] : d[0], dv = major == 2 ? d[1] : d[2];
+    const uint32_t face = static_cast<uint32_t>(2 * major + (dm < 0.0f ? 1 : 0));  // 0..5
+    const float inv = 1.0f / __builtin_fmaxf(__builtin_fabsf(dm), 1e-20f);
+    const float n = static_cast<float>(sectorCells);
+    const uint32_t cu = static_cast<uint32_t>(__builtin_fminf(__builtin_fmaxf((du * inv + 1.0f) * 0.5f * n, 0.0f), n - 1.0f));
+    const uint32_t cv = static_cast<uint32_t>(__builtin_fminf(__builtin_fmaxf((dv * inv + 1.0f) * 0.5f * n, 0.0f), n - 1.0f));
+    // snake order over the face's cells keeps neighbouring sector numbers neighbouring directions
+    const uint32_t column = (cu & 1u) ? static_cast<uint32_t>(sectorCells) - 1u - cv : cv;
+    const uint32_t sector = (face * static_cast<uint32_t>(sectorCells) + cu) * static_cast<uint32_t>(sectorCells) + column;
+    int sectorBits = 0;
+    while ((1u << sectorBits) < 6u * static_cast<uint32_t>(sectorCells * sectorCells)) ++sectorBits;
+    return directionAbove ? (sector << (3 * originBits)) | morton : (morton << sectorBits) | sector;
+}
+
 // Sink selects the deposit path and Record the per-photon path dump at compile time, so
 // that the probe-sink kernel carries neither the splat's shadow-ray cast nor the dump.
 template <int Sink, bool Record, bool Animated>
@@ -737,7 +787,7 @@ __global__ __launch_bounds__(kTraceThreads) void traceKernel(const TraceArgs a)
             }
             if (served && a.queueIn)
             {
-                const PhotonState& parked = a.queueIn[position];
+                const PhotonState& parked = a.queueIn[a.queueInOrder ? a.queueInOrder[position] : position];
                 ray.o = mk(parked.origin[0], parked.origin[1], parked.origin[2]);
                 ray.d = mk(parked.direction[0], parked.direction[1], parked.direction[2]);
                 color = Color{parked.color[0], parked.color[1], parked.color[2]};
@@ -936,6 +986,10 @@ __global__ __launch_bounds__(kTraceThreads) void traceKernel(const TraceArgs a)
                 const unsigned long long slot = base + lanesBelow(parkMask);
                 if (goesOn && slot < a.queueOutCapacity)  // a full queue: the photon stays in its lane
                 {
+                    if (a.queueOutKeys)
+                    {
+                        a.queueOutKeys[slot] = rayKey(a, ray);
+                    }
                     PhotonState& parked = a.queueOut[slot];
                     parked.origin[0] = ray.o.x; parked.origin[1] = ray.o.y; parked.origin[2] = ray.o.z;
                     parked.direction[0] = ray.d.x; parked.direction[1] = ray.d.y; parked.direction[2] = ray.d.z;
@@ -1995,6 +2049,28 @@ hipError_t sortEmissionPairs(void* scratch, size_t* scratchBytes, const uint32_t
     while ((1 << lightBits) < lightCount && lightBits < 8) ++lightBits;
     return hipcub::DeviceRadixSort::SortPairs(scratch, *scratchBytes, keysIn, keysOut, idsIn, idsOut, static_cast<int>(n), 0,
                                               2 * kGlobalAxisBits + lightBits, stream);
+}
+
+namespace
+{
+__global__ void iotaKernel(uint32_t* values, uint64_t n)
+{
+    const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < n) values[i] = static_cast<uint32_t>(i);
+}
+}  // namespace
+
+void launchIota(uint32_t* values, uint64_t n, hipStream_t stream)
+{
+    if (n == 0) return;
+    hipLaunchKernelGGL(iotaKernel, dim3(static_cast<unsigned int>((n + 255) / 256)), dim3(256), 0, stream, values, n);
+}
+
+hipError_t sortPairs32(void* scratch, size_t* scratchBytes, const uint32_t* keysIn, uint32_t* keysOut, const uint32_t* valuesIn,
+                       uint32_t* valuesOut, uint64_t n, int bits, hipStream_t stream)
+{
+    return hipcub::DeviceRadixSort::SortPairs(scratch, *scratchBytes, keysIn, keysOut, valuesIn, valuesOut, static_cast<int>(n), 0,
+                                              bits, stream);
 }
 
 int traceBlockThreads() { return kTraceThreads; }

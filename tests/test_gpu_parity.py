@@ -186,14 +186,20 @@ def test_counters_equal_oracle_at_scale(rt, scene_opener, name, photons):
     assert np.allclose(c["deposited_power"], ref["deposited_power"], rtol=1e-9)
 
 
+@pytest.mark.parametrize("level_sort", ["default", "0", "0x134"])
 @pytest.mark.parametrize("capacity", [1 << 30, 700])
 @pytest.mark.parametrize("name", ["cbgmd", "knot", "mixed", "animated", "furnace"])
-def test_bounce_level_queues_change_nothing(rt, scene_opener, name, capacity, monkeypatch):
+def test_bounce_level_queues_change_nothing(rt, scene_opener, name, capacity, level_sort, monkeypatch):
     """Large passes park the photons that go on after a bounce and trace the next bounce in a
-    launch of its own; a full queue leaves a photon in its lane.  Forced onto small passes here
-    (queue minimum 1), with room for everything and with room for 700 photons per level: paths,
-    counters and the store must equal the oracle's as in a single launch."""
+    launch of its own, walking the parked photons in the order of a key of their rays (origin cell,
+    direction sector); a full queue leaves a photon in its lane.  Forced onto small passes here
+    (queue minimum 1, every level sorted), with room for everything and with room for 700 photons per
+    level, in the default key layout, without the sort and with another layout: paths, counters and
+    the store must equal the oracle's as in a single launch."""
     monkeypatch.setenv("RT_AMD_QUEUE_MIN", "1")
+    monkeypatch.setenv("RT_AMD_LEVEL_SORT_MIN", "1")
+    if level_sort != "default":
+        monkeypatch.setenv("RT_AMD_LEVEL_SORT", level_sort)
     monkeypatch.setenv("RT_AMD_QUEUE_CAPACITY", str(capacity))
     entry = SCENES[name]
     scene, tracer, orc = _open(rt, scene_opener, entry)
