@@ -1369,22 +1369,85 @@ RT_DEV Color gatherRadiance(const GatherArgs& a, const GatherPoint& gp, unsigned
     const Material* material = isEmitter ? nullptr : &a.scene.materials[gp.material];
     Color sum = black;
     unsigned long long kept = 0;
-    // rows of cells along x are contiguous in key order; when the cube is wide, whole z
-    // slabs are scanned and filtered instead of searching every row
+    // Rows of cells along x are contiguous in key order; when the cube is wide, whole z slabs are
+    // scanned and filtered instead of searching every row.  Where the rows start in the key list is
+    // looked up for nine rows at a time (the whole neighbourhood of a footprint that fits a cell), the
+    // nine binary searches advancing in step: their reads, chains of dependent round trips each, are in
+    // flight together, and so are the reads of every row's first key, which tell the empty rows (most of
+    // them, on a thin store) from the ones worth a walk.  The rows are then walked in the reference's
+    // order (z outside, y inside, store order within a cell).
     const bool bySlab = (y1 - y0) > 16;
-    for (int64_t z = z0; z <= z1; ++z)
+    // (a footprint spans at most 2^21 cells along an axis and fewer than 17 rows per slab: 32-bit row numbers)
+    const int rowsPerSlab = bySlab ? 1 : static_cast<int>(y1 - y0 + 1);
+    const int rowCount = static_cast<int>(z1 - z0 + 1) * rowsPerSlab;
+    constexpr int kRows = 9;
+    int steps = 0;
+    while ((1ull << steps) <= a.indexed) ++steps;
+    for (int rowBase = 0; rowBase < rowCount; rowBase += kRows)
     {
-        for (int64_t y = y0; y <= y1; ++y)
+        // the rows' first and last keys are recomputed where they are needed rather than kept (registers)
+        auto firstKey = [&](int k) {
+            const int row = rowBase + k;
+            return row < rowCount ? packCell(x0, y0 + row % rowsPerSlab, z0 + row / rowsPerSlab) : kEmptyKey;
+        };
+        auto lastKey = [&](int k) {
+            const int row = rowBase + k;
+            const int64_t y = y0 + row % rowsPerSlab, z = z0 + row / rowsPerSlab;
+            return bySlab ? packCell(x1, y1, z) : packCell(x1, y, z);
+        };
+        uint32_t lo[kRows], hi[kRows];
+#pragma unroll
+        for (int k = 0; k < kRows; ++k)
         {
-            const unsigned long long first = packCell(x0, y, z);
-            const unsigned long long last = bySlab ? packCell(x1, y1, z) : packCell(x1, y, z);
-            for (uint64_t j = lowerBound(a.keys, a.indexed, first); j < a.indexed; ++j)
+            lo[k] = 0;
+            hi[k] = rowBase + k < rowCount ? static_cast<uint32_t>(a.indexed) : 0u;
+        }
+        for (int step = 0; step < steps; ++step)
+        {
+            unsigned long long probe[kRows];
+#pragma unroll
+            for (int k = 0; k < kRows; ++k)
+            {
+                const uint32_t mid = (lo[k] + hi[k]) >> 1;  // hi <= indexed < 2^31
+                probe[k] = a.keys[mid < a.indexed ? mid : a.indexed - 1];
+            }
+#pragma unroll
+            for (int k = 0; k < kRows; ++k)
+            {
+                const uint32_t mid = (lo[k] + hi[k]) >> 1;
+                const bool open = lo[k] < hi[k];
+                const bool below = probe[k] < firstKey(k);
+                lo[k] = (open && below) ? mid + 1 : lo[k];
+                hi[k] = (open && !below) ? mid : hi[k];
+            }
+        }
+        uint32_t worthAWalk = 0;
+        {
+            unsigned long long head[kRows];
+#pragma unroll
+            for (int k = 0; k < kRows; ++k)
+            {
+                head[k] = lo[k] < a.indexed ? a.keys[lo[k]] : kEmptyKey;
+            }
+#pragma unroll
+            for (int k = 0; k < kRows; ++k)
+            {
+                if (rowBase + k < rowCount && head[k] <= lastKey(k)) worthAWalk |= 1u << k;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kRows; ++k)
+        {
+            if ((worthAWalk & (1u << k)) == 0)
+            {
+                continue;  // no such row, or nothing in it
+            }
+            const unsigned long long lastOfRow = lastKey(k);
+            for (uint64_t j = lo[k]; j < a.indexed; ++j)
             {
                 // The key and the whole 52-byte row are requested together, before any test looks at
                 // them: read field by field behind its test, a row costs up to five dependent round
                 // trips (key, position, time, normal, direction), and the loop is bound by exactly that.
-                // (Requesting the next row ahead of the work on this one gained 8 % on one scene and
-                // lost 14 % on another.)
                 typedef float Float4At4 __attribute__((ext_vector_type(4), aligned(4)));
                 const float* row = a.store + 13ull * j;
                 const unsigned long long key = a.keys[j];
@@ -1393,7 +1456,7 @@ RT_DEV Color gatherRadiance(const GatherArgs& a, const GatherPoint& gp, unsigned
                 Float4At4 q2 = *reinterpret_cast<const Float4At4*>(row + 8);
                 float q3 = row[12];
                 asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3));  // the loads stay here, ahead of the branches
-                if (key > last)
+                if (key > lastOfRow)
                 {
                     break;
                 }
@@ -1455,10 +1518,6 @@ RT_DEV Color gatherRadiance(const GatherArgs& a, const GatherPoint& gp, unsigned
                 sum.g += fp.g;
                 sum.b += fp.b;
                 kept += 1;
-            }
-            if (bySlab)
-            {
-                break;  // the slab scan covered every row of this z
             }
         }
     }

@@ -44,3 +44,13 @@ def test_two_rank_frame_equals_one_rank_frame(tmp_path, scene, photons, probe_ga
         # sums of the same terms in another order
         np.testing.assert_allclose(b, a, rtol=3e-4, atol=2e-6 * max(peak, 1e-30))
     assert lit > 0
+
+
+def test_more_ranks_than_photons(tmp_path):
+    """One photon per light over two ranks: rank 0's share is empty and must trace nothing (a photon
+    count of 0 in rt_trace_params means "all the rest"), so the frame holds each photon once."""
+    one, c1 = render(1, "tests/scenes/mixed.json", 1, True, str(tmp_path / "one"))
+    two, c2 = render(2, "tests/scenes/mixed.json", 1, True, str(tmp_path / "two"))
+    assert c1["photons"] == c2["photons"] == 5  # one per light
+    for k in ("casts", "bounces", "deposits", "kept"):
+        assert c1[k] == c2[k], k
