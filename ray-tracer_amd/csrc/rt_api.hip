@@ -536,8 +536,8 @@ void buildScene(rt_tracer* t, const rt_scene* scene)
             }
         }
         // world-space box of a static volume: its object-space corners through the volume's
-        // transform, grown by a millionth of the scene's scale (the transforms round at 1e-16 of it)
-        // and rounded outward to single precision
+        // transform, grown by a few millionths of the scene's scale (the padding of the trees' boxes:
+        // the test is the same single-precision one) and rounded outward to single precision
         std::vector<std::array<double, 3>> corners;
         if (v.animation < 0)
         {
@@ -584,7 +584,7 @@ void buildScene(rt_tracer* t, const rt_scene* scene)
                 }
             }
             const double grow =
-                1e-6 * sceneScale + (rv.type == RT_VOLUME_SPHERE ? std::fabs(rv.param[3]) * (1.0 + 1e-6) : 0.0);
+                4e-6 * sceneScale + (rv.type == RT_VOLUME_SPHERE ? std::fabs(rv.param[3]) * (1.0 + 1e-6) : 0.0);
             if (finite)
             {
                 v.hasWorldBox = 1;

@@ -324,19 +324,40 @@ RT_DEV bool rayIntersectsBounds(const Ray& ray, const double* bmin, const double
     return true;
 }
 
-// Per-ray constants of the slab and watertight tests (they depend on the ray only).
-struct RayPrep
+// Per-ray constants of the slab test (they depend on the ray only).  A box is six doubles (min xyz,
+// max xyz); nearIdx[i] / farIdx[i] pick the plane of axis i the ray meets first / last, which is what
+// the reference's "swap when t1 > t2" amounts to: the order of the two products follows the sign of
+// the reciprocal.  ood is 1 / direction, or +infinity on an axis the reference treats as parallel
+// (|direction| < epsilon): there (plane - origin) * inf is -inf / +inf while the origin lies between
+// the planes (or NaN on a plane, which the IEEE max / min below ignore) and drives the interval empty
+// when it lies outside, exactly the reference's containment test (src/Ray.cpp:24-32).
+struct SlabPrep
 {
-    // Slab test.  A box is six doubles (min xyz, max xyz); nearIdx[i] / farIdx[i] pick the
-    // plane of axis i the ray meets first / last, which is what the reference's
-    // "swap when t1 > t2" amounts to: the order of the two products follows the sign of
-    // the reciprocal.  ood is 1 / direction, or +infinity on an axis the reference
-    // treats as parallel (|direction| < epsilon): there (plane - origin) * inf is -inf /
-    // +inf while the origin lies between the planes (or NaN on a plane, which the
-    // IEEE max / min below ignore) and drives the interval empty when it lies outside,
-    // exactly the reference's containment test (src/Ray.cpp:24-32).
     double ood[3];
     int32_t nearIdx[3], farIdx[3];
+};
+
+RT_DEV SlabPrep prepareSlab(const Ray& ray)
+{
+    SlabPrep p;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+    {
+        const double d = axisOf(ray.d, i);
+        const bool parallel = dabs(d) < kEps;
+        const double ood = 1.0 / d;
+        p.ood[i] = parallel ? __builtin_inf() : ood;
+        const bool reversed = !parallel && ood < 0.0;
+        p.nearIdx[i] = reversed ? i + 3 : i;
+        p.farIdx[i] = reversed ? i : i + 3;
+    }
+    return p;
+}
+
+// Per-ray constants of the watertight test.  (The three reciprocals of the slab test are not among
+// them: a cast needs the double-precision slab test for few of its rays, see castMesh.)
+struct RayPrep
+{
     int kx, ky, kz;      // watertight axis permutation, src/Ray.cpp:100-139
     double sx, sy, sz;   // shear constants, :141-147
     double okx, oky, okz;  // ray origin in permuted order
@@ -346,19 +367,7 @@ struct RayPrep
 RT_DEV RayPrep prepareRay(const Ray& ray)
 {
     RayPrep p;
-    p.parallel = false;
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-    {
-        const double d = axisOf(ray.d, i);
-        const bool parallel = dabs(d) < kEps;
-        p.parallel = p.parallel || parallel;
-        const double ood = 1.0 / d;
-        p.ood[i] = parallel ? __builtin_inf() : ood;
-        const bool reversed = !parallel && ood < 0.0;
-        p.nearIdx[i] = reversed ? i + 3 : i;
-        p.farIdx[i] = reversed ? i : i + 3;
-    }
+    p.parallel = dabs(ray.d.x) < kEps || dabs(ray.d.y) < kEps || dabs(ray.d.z) < kEps;
     const double adx = dabs(ray.d.x), ady = dabs(ray.d.y), adz = dabs(ray.d.z);
     int kz = 2;
     if (adx > ady && adx > adz)
@@ -396,7 +405,7 @@ RT_DEV RayPrep prepareRay(const Ray& ray)
 // as rayIntersectsBounds.  The reference leaves its loop at the first axis whose
 // interval is empty; the interval only ever shrinks, so testing it once after the last
 // axis gives the same answer.  `box` points at six doubles in memory (min xyz, max xyz).
-RT_DEV bool slabTest(const Ray& ray, const RayPrep& p, const double* box, double* entry)
+RT_DEV bool slabTest(const Ray& ray, const SlabPrep& p, const double* box, double* entry)
 {
     double tmin = 0.0;
     double tmax = kMaxDouble;
@@ -634,16 +643,18 @@ struct RayPrepSingle
     Float2 oA, oB, oC, dA, dB, dC;
 };
 
-RT_DEV RayPrepSingle prepareRaySingle(const Ray& ray, const RayPrep& p)
+RT_DEV RayPrepSingle prepareRaySingle(const Ray& ray)
 {
     float o[3], d[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i)
     {
         o[i] = static_cast<float>(axisOf(ray.o, i));
-        // an axis the ray runs parallel to: a huge finite reciprocal keeps 0 * reciprocal at 0, so
+        // The hardware's reciprocal (one unit in the last place) of the rounded direction: a few
+        // parts in ten million of the parameter, which the boxes' padding covers with room to spare.
+        // An axis the ray runs parallel to: a huge finite reciprocal keeps 0 * reciprocal at 0, so
         // an origin between (or on) the planes gives (-huge, +huge) and one outside an empty interval
-        const float r = static_cast<float>(p.ood[i]);
+        const float r = __builtin_amdgcn_rcpf(static_cast<float>(axisOf(ray.d, i)));
         d[i] = __builtin_fminf(__builtin_fmaxf(r, -1e30f), 1e30f);
     }
     RayPrepSingle q;
@@ -654,6 +665,15 @@ RT_DEV RayPrepSingle prepareRaySingle(const Ray& ray, const RayPrep& p)
     q.dB = Float2{d[2], d[0]};
     q.dC = Float2{d[1], d[2]};
     return q;
+}
+
+// 1 / |direction| in single precision, never too small (2e-6 above what the conversions, the sum and
+// the hardware's reciprocal square root can lose): turns a distance bound into a parameter bound
+// that never prunes too much.
+RT_DEV float reciprocalLengthUp(const Vec& d)
+{
+    const float x = static_cast<float>(d.x), y = static_cast<float>(d.y), z = static_cast<float>(d.z);
+    return __builtin_amdgcn_rsqf(x * x + y * y + z * z) * (1.0f + 2e-6f);
 }
 
 RT_DEV bool slabTestChild(const RayPrepSingle& q, const float* box, float* entry)
@@ -703,15 +723,15 @@ RT_DEV bool castMesh(const SceneView& s, int32_t nodeBase, int32_t nodeCount, in
     RT_DIAG_TRIP(0);  // mesh casts
     const Node* nodes = s.nodes + nodeBase;
     const double* triRec = s.triRec + 16 * triBase;
-    const double dlen = magnitude(ray.d);
+    const float perLength = reciprocalLengthUp(ray.d);
     const double slack = 1e-11 * (extent + dabs(ray.o.x) + dabs(ray.o.y) + dabs(ray.o.z));
     bool found = false;
     double best = kMaxDouble;
     int32_t bestSlot = 0x7fffffff, bestRank = 0x7fffffff;
     double cutoff = bound * (1.0 + 1e-9) + slack;  // kMaxDouble -> +inf: nothing is pruned
     // the same bound as a ray parameter in single precision, rounded up (never prunes too much)
-    float cutoffT = __double2float_ru(cutoff / dlen);
-    const RayPrepSingle single = prepareRaySingle(ray, prep);
+    float cutoffT = __double2float_ru(cutoff) * perLength;
+    const RayPrepSingle single = prepareRaySingle(ray);
 
     constexpr int32_t kDone = kNoChild;    // nothing left to visit
     constexpr int32_t kPop = kNoChild + 1;  // take the next entry of the stack
@@ -848,13 +868,15 @@ RT_DEV bool castMesh(const SceneView& s, int32_t nodeBase, int32_t nodeCount, in
                 {
                     // The reference tests a triangle only when the ray meets its own node's box
                     // (and with it every ancestor's).  Away from the triangle's edges that is
-                    // certain; otherwise, or when the ray runs parallel to an axis, ask the box.
+                    // certain; otherwise, or when the ray runs parallel to an axis, ask the box (in
+                    // double precision, as the reference does: the three reciprocals that takes are
+                    // worked out here, for the few rays that come this way).
                     const double certain = static_cast<double>(__uint_as_float(static_cast<uint32_t>(word >> 32)));
                     const double least = dmin(b3[0], dmin(b3[1], b3[2]));
                     if (prep.parallel || !(least >= certain))
                     {
                         double ignored;
-                        wins = slabTest(ray, prep, rec + 10, &ignored);
+                        wins = slabTest(ray, prepareSlab(ray), rec + 10, &ignored);
                     }
                 }
                 if (wins)
@@ -868,7 +890,7 @@ RT_DEV bool castMesh(const SceneView& s, int32_t nodeBase, int32_t nodeCount, in
                     bary[2] = b3[2];
                     *position = pos;
                     cutoff = dmin(best, bound) * (1.0 + 1e-9) + slack;
-                    cutoffT = __double2float_ru(cutoff / dlen);
+                    cutoffT = __double2float_ru(cutoff) * perLength;
                 }
             }
         }
@@ -1009,16 +1031,8 @@ RT_DEV bool castScene(const SceneView& s, const Ray& ray, float time, double sel
     bool valid = false;
     Vec bestPos = mk(0, 0, 0), bestNrm = mk(0, 0, 0);
     int32_t bestVolume = -1, bestTri = -1;
-    // reciprocal direction of the world ray for the per-volume box test (+inf on an axis the ray
-    // runs parallel to: the slab arithmetic then reduces to containment, as in slabTest)
-    double worldOod[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-    {
-        const double d = axisOf(ray.d, i);
-        worldOod[i] = dabs(d) < kEps ? __builtin_inf() : 1.0 / d;
-    }
-    const double worldLength = magnitude(ray.d);
+    // the per-volume box test runs in single precision against padded boxes, as in castMesh
+    const float perWorldLength = reciprocalLengthUp(ray.d);
     Ray local;
     local.o = local.d = mk(0, 0, 0);
     RayPrep prep = {};
@@ -1030,18 +1044,21 @@ RT_DEV bool castScene(const SceneView& s, const Ray& ray, float time, double sel
         const int32_t type = vol->type;
         if (vol->hasWorldBox)
         {
-            double tmin = 0.0, tmax = kMaxDouble;
+            float box[6], entry;
 #pragma unroll
-            for (int i = 0; i < 3; ++i)
+            for (int k = 0; k < 6; ++k)
             {
-                const double origin = axisOf(ray.o, i);
-                const double t1 = (static_cast<double>(vol->worldBox[i]) - origin) * worldOod[i];
-                const double t2 = (static_cast<double>(vol->worldBox[3 + i]) - origin) * worldOod[i];
-                const bool reversed = worldOod[i] < 0.0;
-                tmin = __builtin_fmax(tmin, reversed ? t2 : t1);
-                tmax = __builtin_fmin(tmax, reversed ? t1 : t2);
+                box[k] = vol->worldBox[k];
             }
-            if (tmin > tmax || tmin * worldLength > minDistance * (1.0 + 1e-9))
+            // The world ray's single-precision form is worked out again for every volume (a dozen
+            // instructions): kept across the casts it would hold twelve registers the kernel does
+            // not have.  The empty statement keeps the compiler from keeping it all the same.
+            Ray here = ray;
+            asm volatile("" : "+v"(here.d.x), "+v"(here.d.y), "+v"(here.d.z));
+            const RayPrepSingle worldSingle = prepareRaySingle(here);
+            // missed, or entered beyond the closest hit so far (as a parameter bound rounded up)
+            if (!slabTestChild(worldSingle, box, &entry) ||
+                entry > __double2float_ru(minDistance * (1.0 + 1e-9)) * perWorldLength)
             {
                 continue;
             }

@@ -1117,7 +1117,7 @@ __global__ void intersectKernel(int kind, int64_t n, const double* in, void* out
             hi[k] = dmax(r[6 + k], r[9 + k]);
         }
         const bool direct = rayIntersectsBounds(ray, lo, hi, &entry);
-        const RayPrep prep = prepareRay(ray);
+        const SlabPrep prep = prepareSlab(ray);
         // the hoisted test reads its box from memory: stage the sorted corners after the
         // row's own output slot is known to be free (rows are 12 doubles, the box is 6)
         double* box = const_cast<double*>(r) + 6;

@@ -91,7 +91,10 @@ def tracer_lib():
         if not os.path.exists(TRACER_LIB_PATH):
             raise RuntimeError(f"{TRACER_LIB_PATH} is not built; run __graft_entry__.build() "
                                "(there is no CPU fallback for the photon pass)")
-        lib = C.CDLL(TRACER_LIB_PATH)
+        # Another build named by RT_AMD_LIBRARY binds its own symbols first: the host library has
+        # already brought the regular build into the process, whose symbols would otherwise win.
+        override = bool(os.environ.get("RT_AMD_LIBRARY"))
+        lib = C.CDLL(TRACER_LIB_PATH, mode=(os.RTLD_NOW | os.RTLD_DEEPBIND) if override else C.DEFAULT_MODE)
         for name, (restype, argtypes) in _SIGNATURES.items():
             fn = getattr(lib, name)
             fn.restype = restype
