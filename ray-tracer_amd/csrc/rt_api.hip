@@ -249,6 +249,12 @@ struct rt_tracer
         DeviceArray<uint32_t> orderIn, orderOut;
         DeviceArray<unsigned char> scratch;
         DeviceArray<float> sortedStore;
+        DeviceArray<int32_t> cellBox;     // [0..2] least, [3..5] greatest cell x, y, z of the records that pack
+        DeviceArray<uint32_t> cellStart;  // directory of the sorted keys over that box (GatherArgs::cellStart)
+        DeviceArray<unsigned char> directoryScratch;
+        DeviceArray<uint32_t> heavyPixels;  // pixels the one-lane gather leaves to a wave each
+        int32_t cellMin[3] = {0, 0, 0}, cellDim[3] = {0, 0, 0};
+        int32_t directoryKind = 0;  // rtd::kDirectory...
         // the index these arrays hold: valid while the store has not changed since (storeVersion)
         uint64_t indexedVersion = 0, indexedRecords = 0, indexed = 0;
         double indexedCellSize = 0.0;
@@ -2261,7 +2267,11 @@ int32_t rt_gather(rt_tracer* tracer, int32_t camera, double gather_cell_size, do
                 orderIn.allocate(n);
                 orderOut.allocate(n);
             }
-            rtd::launchStoreKeys(tracer->storeRecords.ptr, n, 1.0 / cellSize, keysIn.ptr, orderIn.ptr, tracer->stream);
+            if (g.cellBox.count == 0) g.cellBox.allocate(6);
+            const int32_t emptyBox[6] = {INT32_MAX, INT32_MAX, INT32_MAX, INT32_MIN, INT32_MIN, INT32_MIN};
+            check(hipMemcpy(g.cellBox.ptr, emptyBox, sizeof(emptyBox), hipMemcpyHostToDevice), "hipMemcpy cell box");
+            rtd::launchStoreKeys(tracer->storeRecords.ptr, n, 1.0 / cellSize, keysIn.ptr, orderIn.ptr, g.cellBox.ptr,
+                                 tracer->stream);
             check(hipGetLastError(), "store keys launch");
             size_t bytes = 0;
             check(rtd::sortStoreKeys(nullptr, &bytes, keysIn.ptr, keysOut.ptr, orderIn.ptr, orderOut.ptr, n, tracer->stream),
@@ -2278,11 +2288,61 @@ int32_t rt_gather(rt_tracer* tracer, int32_t camera, double gather_cell_size, do
                   "hipMemcpyAsync indexed");
             check(hipStreamSynchronize(tracer->stream), "hipStreamSynchronize");
             indexed = hostIndexed;
+            g.directoryKind = rtd::kDirectoryNone;
             if (indexed > 0)
             {
                 if (sortedStore.count < 13 * indexed) sortedStore.allocate(13 * n);
                 rtd::launchReorderStore(tracer->storeRecords.ptr, orderOut.ptr, indexed, sortedStore.ptr, tracer->stream);
                 check(hipGetLastError(), "store reorder launch");
+                // Directory of the sorted keys: where every cell of the box around the records starts.
+                // The gather then reads a row's range instead of searching for it.  A box of more cells
+                // than the limit (small cells in a large scene) gets a directory of its rows of cells
+                // instead, within which the gather searches; one with more rows than that goes without.
+                // (RT_AMD_GATHER_DIRECTORY=0 turns it off, any other number is the limit in entries)
+                int32_t box[6];
+                check(hipMemcpy(box, g.cellBox.ptr, sizeof(box), hipMemcpyDeviceToHost), "hipMemcpy cell box");
+                uint64_t limit = 1ull << 27;
+                if (const char* v = std::getenv("RT_AMD_GATHER_DIRECTORY")) limit = std::strtoull(v, nullptr, 10);
+                uint64_t cells = 0;
+                bool fits = false;
+                g.directoryKind = rtd::kDirectoryNone;
+                if (limit > 0 && box[0] <= box[3] && box[1] <= box[4] && box[2] <= box[5])
+                {
+                    uint64_t dim[3];
+                    for (int k = 0; k < 3; ++k)
+                    {
+                        g.cellMin[k] = box[k];
+                        dim[k] = static_cast<uint64_t>(static_cast<int64_t>(box[3 + k]) - box[k] + 1);
+                    }
+                    if (dim[1] * dim[2] <= limit)  // (each below 2^21: no overflow)
+                    {
+                        fits = true;
+                        g.directoryKind = dim[0] * dim[1] * dim[2] <= limit ? rtd::kDirectoryCells : rtd::kDirectoryRows;
+                        if (g.directoryKind == rtd::kDirectoryRows)
+                        {
+                            dim[0] = 1;
+                            g.cellMin[0] = INT32_MIN;
+                        }
+                        cells = dim[0] * dim[1] * dim[2];
+                        for (int k = 0; k < 3; ++k)
+                        {
+                            g.cellDim[k] = static_cast<int32_t>(dim[k]);
+                        }
+                    }
+                }
+                if (fits)
+                {
+                    if (g.cellStart.count < cells + 1) g.cellStart.allocate(cells + 1);
+                    size_t directoryBytes = 0;
+                    check(rtd::buildCellDirectory(nullptr, &directoryBytes, keysOut.ptr, indexed, g.cellMin, g.cellDim,
+                                                  g.cellStart.ptr, tracer->stream),
+                          "directory size query");
+                    if (g.directoryScratch.count < directoryBytes) g.directoryScratch.allocate(directoryBytes > 0 ? directoryBytes : 1);
+                    check(rtd::buildCellDirectory(g.directoryScratch.ptr, &directoryBytes, keysOut.ptr, indexed, g.cellMin,
+                                                  g.cellDim, g.cellStart.ptr, tracer->stream),
+                          "cell directory");
+                    check(hipGetLastError(), "cell directory");
+                }
             }
         }
         g.indexedVersion = tracer->storeVersion;
@@ -2305,6 +2365,13 @@ int32_t rt_gather(rt_tracer* tracer, int32_t camera, double gather_cell_size, do
         args.offsets = cache.offsets.ptr;
         args.points = cache.devicePoints.ptr;
         args.stats = stats.ptr;
+        args.directoryKind = indexed > 0 ? g.directoryKind : rtd::kDirectoryNone;
+        args.cellStart = args.directoryKind != rtd::kDirectoryNone ? g.cellStart.ptr : nullptr;
+        for (int k = 0; k < 3; ++k)
+        {
+            args.cellMin[k] = g.cellMin[k];
+            args.cellDim[k] = g.cellDim[k];
+        }
         if (cache.total > 0)
         {
             // Lanes per sampled pixel, by how many records a gather point meets on average: a few
@@ -2313,8 +2380,29 @@ int32_t rt_gather(rt_tracer* tracer, int32_t camera, double gather_cell_size, do
             const uint64_t perPoint = indexed / std::max<uint64_t>(1, cache.total);
             int lanes = perPoint >= 64 ? 64 : (perPoint >= 3 ? 8 : 1);
             if (const char* v = std::getenv("RT_AMD_GATHER_LANES")) lanes = std::atoi(v);
-            rtd::launchGather(args, lanes, tracer->stream);
+            // One lane per pixel, with the directory: a pixel that looks at a crowded spot (an emitter's
+            // deposits, a caustic) is handed to a wave of its own instead of holding up its wave.
+            // (RT_AMD_GATHER_HEAVY=<records> sets the limit, 0 turns the hand-over off)
+            uint32_t heavy = 256;
+            if (const char* v = std::getenv("RT_AMD_GATHER_HEAVY")) heavy = static_cast<uint32_t>(std::strtoul(v, nullptr, 10));
+            if (lanes < 8 && heavy != 0 && cache.pixels < (1ll << 32))
+            {
+                if (g.heavyPixels.count < static_cast<size_t>(cache.pixels)) g.heavyPixels.allocate(static_cast<size_t>(cache.pixels));
+                check(hipMemsetAsync(stats.ptr + 3, 0, sizeof(unsigned long long), tracer->stream), "hipMemsetAsync heavy count");
+                args.heavyThreshold = heavy;
+                args.heavyPixels = g.heavyPixels.ptr;
+                args.heavyCount = stats.ptr + 3;
+            }
+            rtd::launchGather(args, lanes, tracer->computeUnits, tracer->stream);
             check(hipGetLastError(), "gather launch");
+            if (args.heavyThreshold != 0 && std::getenv("RT_AMD_VERBOSE") != nullptr)
+            {
+                unsigned long long handedOver = 0;
+                check(hipMemcpy(&handedOver, stats.ptr + 3, sizeof(handedOver), hipMemcpyDeviceToHost), "hipMemcpy heavy count");
+                std::fprintf(stderr, "[rt_amd] gather: directory kind %d (%d x %d x %d), %llu of %lld pixels handed to a wave each\n",
+                             args.directoryKind, args.cellDim[0], args.cellDim[1], args.cellDim[2], handedOver,
+                             static_cast<long long>(cache.pixels));
+            }
         }
         unsigned long long hostStats[2] = {0, 0};
         check(hipMemcpyAsync(hostStats, stats.ptr, sizeof(hostStats), hipMemcpyDeviceToHost, tracer->stream),

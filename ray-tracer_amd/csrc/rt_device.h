@@ -1040,6 +1040,7 @@ RT_DEV bool castScene(const SceneView& s, const Ray& ray, float time, double sel
     bool prepared = false;  // `prep` belongs to `local`
     for (int32_t v = 0; v < s.volumeCount; ++v)
     {
+        RT_DIAG_TIC(boxStart);
         const auto vol = uniformRead(s.volumes + v);  // v is the same in every lane
         const int32_t type = vol->type;
         if (vol->hasWorldBox)
@@ -1060,9 +1061,12 @@ RT_DEV bool castScene(const SceneView& s, const Ray& ray, float time, double sel
             if (!slabTestChild(worldSingle, box, &entry) ||
                 entry > __double2float_ru(minDistance * (1.0 + 1e-9)) * perWorldLength)
             {
+                RT_DIAG_TOC(boxStart, 7);
                 continue;
             }
         }
+        RT_DIAG_TOC(boxStart, 7);
+        RT_DIAG_TIC(poseStart);
         // the ray in the volume's object space, and what the mesh tests derive from it: kept while
         // the volumes that follow share the pose (the walls of a room are one pose)
         if (vol->poseId != heldPose)
@@ -1091,6 +1095,7 @@ RT_DEV bool castScene(const SceneView& s, const Ray& ray, float time, double sel
                 prep = prepareRay(local);
                 prepared = true;
             }
+            RT_DIAG_TOC(poseStart, 8);
             double bary[3];
             int32_t slot = 0;
             const int64_t triBase = vol->triBase;
@@ -1107,6 +1112,7 @@ RT_DEV bool castScene(const SceneView& s, const Ray& ray, float time, double sel
                 found = castMesh<false>(s, vol->nodeBase, vol->nodeCount, triBase, vol->extent, local, prep, stack, minDistance,
                                         bary, &pos, &dist, &slot);
             }
+            RT_DIAG_TIC(normalStart);
             if (found && dist < minDistance && dist > selfHit)
             {
                 if (needSurface)
@@ -1119,6 +1125,7 @@ RT_DEV bool castScene(const SceneView& s, const Ray& ray, float time, double sel
             {
                 found = false;
             }
+            RT_DIAG_TOC(normalStart, 9);
         }
         else if (type == RT_VOLUME_SPHERE)
         {
@@ -1152,6 +1159,7 @@ RT_DEV bool castScene(const SceneView& s, const Ray& ray, float time, double sel
         }
     }
     out->distance = minDistance;
+    RT_DIAG_TIC(worldStart);
     if (valid && needSurface)
     {
         const Volume& vol = s.volumes[bestVolume];
@@ -1169,6 +1177,7 @@ RT_DEV bool castScene(const SceneView& s, const Ray& ray, float time, double sel
         out->volume = bestVolume;
         out->triangle = bestTri;
     }
+    RT_DIAG_TOC(worldStart, 10);
     return valid;
 }
 

@@ -168,6 +168,13 @@ void launchGatherCount(const SceneView& scene, int32_t camera, int32_t stride, i
 void launchGatherWrite(const SceneView& scene, int32_t camera, int32_t stride, int64_t pixels, const uint32_t* counts,
                        const uint64_t* offsets, GatherPoint* out, hipStream_t stream);
 // The gather (ProbeGather::run) over the bounce store of the last pass.
+enum : int32_t
+{
+    kDirectoryNone = 0,
+    kDirectoryCells = 1,
+    kDirectoryRows = 2
+};
+
 struct GatherArgs
 {
     SceneView scene;
@@ -183,9 +190,32 @@ struct GatherArgs
     const uint64_t* offsets;            // first gather point of each sampled pixel
     const GatherPoint* points;
     unsigned long long* stats;          // [0] contributions added, [1] deposits summed
+    // Directory of the key list over the box of cells that hold records.  kDirectoryCells:
+    // cellStart[c] = first record of cell c or, when the cell is empty, of the next cell that is not;
+    // c = ((z - cellMin[2]) * cellDim[1] + (y - cellMin[1])) * cellDim[0] + (x - cellMin[0]), which
+    // ascends with the keys; cellStart[number of cells] = indexed.  kDirectoryRows (the box has too many
+    // cells): the same over whole rows of cells along x (cellDim[0] = 1, cellMin[0] = INT32_MIN); a
+    // row's records are then searched for the cells wanted.  kDirectoryNone: the whole list is searched.
+    int32_t directoryKind;
+    const uint32_t* cellStart;
+    int32_t cellMin[3], cellDim[3];
+    // One lane per pixel, with the directory: a pixel one of whose gather points has more than
+    // heavyThreshold records in its rows of cells is left to a second launch, a wave per pixel, and
+    // appended to heavyPixels (heavyCount: how many so far).  0: every pixel is done where it is.
+    uint32_t heavyThreshold;
+    uint32_t* heavyPixels;
+    unsigned long long* heavyCount;
+    // Second launch: the pixels to work on (null: all of them, thread by thread)
+    const uint32_t* pixelList;
+    const unsigned long long* pixelListCount;
 };
+// cellBox (may be null): [0..2] least and [3..5] greatest x, y, z of the cells that pack, to be
+// preset to INT32_MAX / INT32_MIN
 void launchStoreKeys(const float* store, uint64_t n, double invCellSize, unsigned long long* keys, uint32_t* order,
-                     hipStream_t stream);
+                     int32_t* cellBox, hipStream_t stream);
+// The directory GatherArgs::cellStart describes, from the sorted keys: `cells` + 1 entries.
+hipError_t buildCellDirectory(void* scratch, size_t* scratchBytes, const unsigned long long* sortedKeys, uint64_t indexed,
+                              const int32_t cellMin[3], const int32_t cellDim[3], uint32_t* cellStart, hipStream_t stream);
 // Stable ascending sort of (keys, order).
 hipError_t sortStoreKeys(void* scratch, size_t* scratchBytes, const unsigned long long* keysIn,
                          unsigned long long* keysOut, const uint32_t* orderIn, uint32_t* orderOut, uint64_t n,
@@ -196,7 +226,9 @@ void launchCountIndexed(const unsigned long long* sortedKeys, uint64_t n, unsign
 // records from consecutive rows instead of chasing the sort's permutation record by record.
 void launchReorderStore(const float* store, const uint32_t* order, uint64_t indexed, float* sorted, hipStream_t stream);
 // lanesPerPixel: 1, 8 or 64 lanes work on one sampled pixel's records (same additions in the same order)
-void launchGather(const GatherArgs& args, int lanesPerPixel, hipStream_t stream);
+// (with one lane and GatherArgs::heavyThreshold set, a second launch on a grid sized for computeUnits
+// takes the pixels the first one left over)
+void launchGather(const GatherArgs& args, int lanesPerPixel, int computeUnits, hipStream_t stream);
 // Device-side build of the probe grid (rt_set_probes): see the kernels in rt_kernels.hip.
 struct ProbeBuild
 {

@@ -1292,18 +1292,85 @@ RT_DEV unsigned long long packCell(int64_t x, int64_t y, int64_t z)
 }
 
 __global__ void storeKeysKernel(const float* store, uint64_t n, double invCellSize, unsigned long long* keys,
-                                uint32_t* order)
+                                uint32_t* order, int32_t* cellBox)
 {
     const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float* r = store + 13 * i;
-    const int64_t x = static_cast<int64_t>(__builtin_floor(static_cast<double>(r[0]) * invCellSize));
-    const int64_t y = static_cast<int64_t>(__builtin_floor(static_cast<double>(r[1]) * invCellSize));
-    const int64_t z = static_cast<int64_t>(__builtin_floor(static_cast<double>(r[2]) * invCellSize));
-    const bool fits = x >= -kPackLimit && x < kPackLimit && y >= -kPackLimit && y < kPackLimit && z >= -kPackLimit &&
-                      z < kPackLimit;
-    keys[i] = fits ? packCell(x, y, z) : kEmptyKey;
-    order[i] = static_cast<uint32_t>(i);
+    int32_t low[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, high[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
+    if (i < n)
+    {
+        const float* r = store + 13 * i;
+        const int64_t x = static_cast<int64_t>(__builtin_floor(static_cast<double>(r[0]) * invCellSize));
+        const int64_t y = static_cast<int64_t>(__builtin_floor(static_cast<double>(r[1]) * invCellSize));
+        const int64_t z = static_cast<int64_t>(__builtin_floor(static_cast<double>(r[2]) * invCellSize));
+        const bool fits = x >= -kPackLimit && x < kPackLimit && y >= -kPackLimit && y < kPackLimit && z >= -kPackLimit &&
+                          z < kPackLimit;
+        keys[i] = fits ? packCell(x, y, z) : kEmptyKey;
+        order[i] = static_cast<uint32_t>(i);
+        if (fits)
+        {
+            low[0] = high[0] = static_cast<int32_t>(x);
+            low[1] = high[1] = static_cast<int32_t>(y);
+            low[2] = high[2] = static_cast<int32_t>(z);
+        }
+    }
+    if (cellBox == nullptr) return;
+    // the box of the cells that pack: one pair of atomics per wave and axis
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+    {
+#pragma unroll
+        for (int step = 1; step < 64; step <<= 1)
+        {
+            low[k] = min(low[k], __shfl_xor(low[k], step));
+            high[k] = max(high[k], __shfl_xor(high[k], step));
+        }
+    }
+    if ((threadIdx.x & 63) == 0 && low[0] <= high[0])
+    {
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+        {
+            // the box settles after a few waves: look before asking for the atomic, or every wave of
+            // the launch queues up at the same six words
+            if (low[k] < __hip_atomic_load(cellBox + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(cellBox + k, low[k]);
+            if (high[k] > __hip_atomic_load(cellBox + 3 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            {
+                atomicMax(cellBox + 3 + k, high[k]);
+            }
+        }
+    }
+}
+
+// Where a cell's records start in the sorted key list (GatherArgs::cellStart).
+struct CellBox
+{
+    int32_t low[3], dim[3];  // dim[0] == 1 with low[0] == INT32_MIN: rows, whatever their cells
+};
+
+RT_DEV uint32_t cellNumber(const CellBox& box, unsigned long long key)
+{
+    const int32_t x = box.low[0] == INT32_MIN
+                          ? 0
+                          : static_cast<int32_t>(static_cast<int64_t>(key & ((1ull << 21) - 1)) - kPackLimit) - box.low[0];
+    const int32_t y = static_cast<int32_t>(static_cast<int64_t>((key >> 21) & ((1ull << 21) - 1)) - kPackLimit) - box.low[1];
+    const int32_t z = static_cast<int32_t>(static_cast<int64_t>(key >> 42) - kPackLimit) - box.low[2];
+    return static_cast<uint32_t>((z * box.dim[1] + y) * box.dim[0] + x);
+}
+
+// every cell's first record; cells without records keep the fill value (no record: UINT32_MAX)
+__global__ void cellFirstsKernel(const unsigned long long* keys, uint64_t indexed, CellBox box, uint32_t* cellStart)
+{
+    const uint64_t j = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (j >= indexed) return;
+    if (j == 0)
+    {
+        cellStart[box.dim[0] * box.dim[1] * box.dim[2]] = static_cast<uint32_t>(indexed);  // the end of the last cell
+    }
+    const uint32_t cell = cellNumber(box, keys[j]);
+    if (j == 0 || cellNumber(box, keys[j - 1]) != cell)
+    {
+        cellStart[cell] = static_cast<uint32_t>(j);
+    }
 }
 
 RT_DEV uint64_t lowerBound(const unsigned long long* keys, uint64_t n, unsigned long long key)
@@ -1333,8 +1400,59 @@ __global__ void countIndexedKernel(const unsigned long long* keys, uint64_t n, u
 
 RT_DEV int64_t clampCell(int64_t v) { return v < -kPackLimit ? -kPackLimit : (v > kPackLimit - 1 ? kPackLimit - 1 : v); }
 
+// The directory entries that bound the records of cells x0..x1 of the rows ya..yb of slab z: the
+// records lie in [cellStart[*from], cellStart[*to]) — exactly those records with a directory of cells
+// and one row (ya == yb), otherwise a range that holds them.  *from >= *to: there are none.  Returns
+// false without a directory: then the whole list is the range (*from < *to still says "maybe").
+RT_DEV bool directoryEntries(const GatherArgs& a, int64_t x0, int64_t x1, int64_t ya, int64_t yb, int64_t z, uint32_t* from,
+                             uint32_t* to)
+{
+    if (a.directoryKind == kDirectoryNone)
+    {
+        *from = 0;
+        *to = 1;
+        return false;
+    }
+    const int64_t xmin = a.cellMin[0], ymin = a.cellMin[1], zmin = a.cellMin[2];
+    const int64_t nx = a.cellDim[0], ny = a.cellDim[1], nz = a.cellDim[2];  // nx is 1 in a directory of rows
+    *from = *to = 0;
+    if (z < zmin || z >= zmin + nz)
+    {
+        return true;
+    }
+    const int64_t ylo = ya < ymin ? ymin : ya, yhi = yb > ymin + ny - 1 ? ymin + ny - 1 : yb;
+    if (ylo > yhi)
+    {
+        return true;
+    }
+    int64_t xa = 0, xb = 0;  // cells of the row, relative to its first
+    if (a.directoryKind == kDirectoryCells && ya == yb)
+    {
+        xa = (x0 < xmin ? xmin : x0) - xmin;
+        xb = (x1 > xmin + nx - 1 ? xmin + nx - 1 : x1) - xmin;
+        if (xa > xb)
+        {
+            return true;
+        }
+    }
+    else
+    {
+        xb = nx - 1;  // whole rows
+    }
+    *from = static_cast<uint32_t>(((z - zmin) * ny + (ylo - ymin)) * nx + xa);
+    *to = static_cast<uint32_t>(((z - zmin) * ny + (yhi - ymin)) * nx + xb + 1);
+    return true;
+}
+
 // testing::gatherRadiance, reference src/ProbeGather.cpp:596-728, for one gather point.
-RT_DEV Color gatherRadiance(const GatherArgs& a, const GatherPoint& gp, unsigned long long* deposits)
+constexpr int kGatherThreads = 256;  // threads of a gather block
+constexpr int kGatherQueue = 16;     // records a lane of the one-lane gather queues before it settles them
+
+// queue: the lane's column of the block's [kGatherQueue][kGatherThreads] words of LDS
+// *heavy is set (and nothing else is done) when the point has more records to look at than
+// a.heavyThreshold allows one lane.
+RT_DEV Color gatherRadiance(const GatherArgs& a, const GatherPoint& gp, uint32_t* queue, unsigned long long* deposits,
+                            bool* heavy)
 {
     const Color black{0.0f, 0.0f, 0.0f};
     const bool isEmitter = gp.material < 0;
@@ -1381,8 +1499,56 @@ RT_DEV Color gatherRadiance(const GatherArgs& a, const GatherPoint& gp, unsigned
     const int rowsPerSlab = bySlab ? 1 : static_cast<int>(y1 - y0 + 1);
     const int rowCount = static_cast<int>(z1 - z0 + 1) * rowsPerSlab;
     constexpr int kRows = 9;
-    int steps = 0;
-    while ((1ull << steps) <= a.indexed) ++steps;
+    // Records that lie within the footprint (and the shutter's window) wait in the lane's queue, in
+    // their order, and go through the remaining tests and the BRDF together: were each taken where
+    // it is found, the wave would run the BRDF for nearly every record any of its lanes looks at,
+    // a few lanes at a time.  The sums are added in the order of the records either way.
+    typedef float Float4At4 __attribute__((ext_vector_type(4), aligned(4)));
+    int queued = 0;
+    auto settle = [&]() {
+        for (int q = 0; q < queued; ++q)
+        {
+            const float* rec = a.store + 13ull * queue[q * kGatherThreads];
+            const Float4At4 q0 = *reinterpret_cast<const Float4At4*>(rec);
+            const Float4At4 q1 = *reinterpret_cast<const Float4At4*>(rec + 4);
+            const Float4At4 q2 = *reinterpret_cast<const Float4At4*>(rec + 8);
+            const Vec dn = mk(q1.z, q1.w, q2.x);
+            const Color power{q2.z, q2.w, rec[12]};
+            if (isEmitter)
+            {
+                if (dot(dn, normal) < 0.5)
+                {
+                    continue;
+                }
+                sum.r += power.r;
+                sum.g += power.g;
+                sum.b += power.b;
+                kept += 1;
+                continue;
+            }
+            const double dnLen = magnitude(dn);
+            if (dnLen > 1e-4)
+            {
+                if (dot(dn / dnLen, normal) < 0.5)
+                {
+                    continue;
+                }
+            }
+            const double planeDist = dabs(dot(mk(q0.x, q0.y, q0.z) - position, normal));
+            if (planeDist > planeBand)
+            {
+                continue;
+            }
+            const Vec wi = neg(mk(q0.w, q1.x, q1.y));
+            const Color f = evaluateMaterial(*material, wi, wo, normal);
+            const Color fp = f * power;
+            sum.r += fp.r;
+            sum.g += fp.g;
+            sum.b += fp.b;
+            kept += 1;
+        }
+        queued = 0;
+    };
     for (int rowBase = 0; rowBase < rowCount; rowBase += kRows)
     {
         // the rows' first and last keys are recomputed where they are needed rather than kept (registers)
@@ -1395,45 +1561,97 @@ RT_DEV Color gatherRadiance(const GatherArgs& a, const GatherPoint& gp, unsigned
             const int64_t y = y0 + row % rowsPerSlab, z = z0 + row / rowsPerSlab;
             return bySlab ? packCell(x1, y1, z) : packCell(x1, y, z);
         };
+        // Records [lo, hi) of every row.  With a directory of cells these are two of its entries; with a
+        // directory of rows (or none) the entries (or the whole list) bound two binary searches, for the
+        // row's first key and for the first key beyond its last.
         uint32_t lo[kRows], hi[kRows];
 #pragma unroll
         for (int k = 0; k < kRows; ++k)
         {
-            lo[k] = 0;
-            hi[k] = rowBase + k < rowCount ? static_cast<uint32_t>(a.indexed) : 0u;
+            const int row = rowBase + k;
+            uint32_t from = 0, to = 0;
+            const bool listed = directoryEntries(a, x0, x1, y0 + row % rowsPerSlab, bySlab ? y1 : y0 + row % rowsPerSlab,
+                                                 z0 + row / rowsPerSlab, &from, &to);
+            const bool any = row < rowCount && from < to;
+            lo[k] = any ? (listed ? a.cellStart[from] : 0u) : 0u;
+            hi[k] = any ? (listed ? a.cellStart[to] : static_cast<uint32_t>(a.indexed)) : 0u;
         }
-        for (int step = 0; step < steps; ++step)
+        if (a.directoryKind != kDirectoryCells)
         {
-            unsigned long long probe[kRows];
+            uint32_t widest = 0;
 #pragma unroll
             for (int k = 0; k < kRows; ++k)
             {
-                const uint32_t mid = (lo[k] + hi[k]) >> 1;  // hi <= indexed < 2^31
-                probe[k] = a.keys[mid < a.indexed ? mid : a.indexed - 1];
+                widest = max(widest, hi[k] - lo[k]);
             }
+            int steps = 0;
+            while ((1u << steps) <= widest) ++steps;
+            uint32_t end[kRows];
 #pragma unroll
             for (int k = 0; k < kRows; ++k)
             {
-                const uint32_t mid = (lo[k] + hi[k]) >> 1;
-                const bool open = lo[k] < hi[k];
-                const bool below = probe[k] < firstKey(k);
-                lo[k] = (open && below) ? mid + 1 : lo[k];
-                hi[k] = (open && !below) ? mid : hi[k];
+                end[k] = hi[k];
+            }
+            // first key of the row or above: [lo, hi) closes in on it
+            for (int step = 0; step < steps; ++step)
+            {
+                unsigned long long probe[kRows];
+#pragma unroll
+                for (int k = 0; k < kRows; ++k)
+                {
+                    const uint32_t mid = (lo[k] + hi[k]) >> 1;  // hi <= indexed < 2^31
+                    probe[k] = a.keys[mid < a.indexed ? mid : a.indexed - 1];
+                }
+#pragma unroll
+                for (int k = 0; k < kRows; ++k)
+                {
+                    const uint32_t mid = (lo[k] + hi[k]) >> 1;
+                    const bool open = lo[k] < hi[k];
+                    const bool below = probe[k] < firstKey(k);
+                    lo[k] = (open && below) ? mid + 1 : lo[k];
+                    hi[k] = (open && !below) ? mid : hi[k];
+                }
+            }
+            // first key beyond the row's last, from there on: [hi, end) closes in on it
+#pragma unroll
+            for (int k = 0; k < kRows; ++k)
+            {
+                hi[k] = lo[k];
+            }
+            for (int step = 0; step < steps; ++step)
+            {
+                unsigned long long probe[kRows];
+#pragma unroll
+                for (int k = 0; k < kRows; ++k)
+                {
+                    const uint32_t mid = (hi[k] + end[k]) >> 1;
+                    probe[k] = a.keys[mid < a.indexed ? mid : a.indexed - 1];
+                }
+#pragma unroll
+                for (int k = 0; k < kRows; ++k)
+                {
+                    const uint32_t mid = (hi[k] + end[k]) >> 1;
+                    const bool open = hi[k] < end[k];
+                    const bool within = probe[k] <= lastKey(k);
+                    hi[k] = (open && within) ? mid + 1 : hi[k];
+                    end[k] = (open && !within) ? mid : end[k];
+                }
             }
         }
-        uint32_t worthAWalk = 0;
+        uint32_t worthAWalk = 0, records = 0;
+#pragma unroll
+        for (int k = 0; k < kRows; ++k)
         {
-            unsigned long long head[kRows];
-#pragma unroll
-            for (int k = 0; k < kRows; ++k)
+            if (lo[k] < hi[k])
             {
-                head[k] = lo[k] < a.indexed ? a.keys[lo[k]] : kEmptyKey;
+                worthAWalk |= 1u << k;
+                records += hi[k] - lo[k];
             }
-#pragma unroll
-            for (int k = 0; k < kRows; ++k)
-            {
-                if (rowBase + k < rowCount && head[k] <= lastKey(k)) worthAWalk |= 1u << k;
-            }
+        }
+        if (a.heavyThreshold != 0 && records > a.heavyThreshold)
+        {
+            *heavy = true;
+            return black;
         }
 #pragma unroll
         for (int k = 0; k < kRows; ++k)
@@ -1442,85 +1660,70 @@ RT_DEV Color gatherRadiance(const GatherArgs& a, const GatherPoint& gp, unsigned
             {
                 continue;  // no such row, or nothing in it
             }
-            const unsigned long long lastOfRow = lastKey(k);
-            for (uint64_t j = lo[k]; j < a.indexed; ++j)
+            // The walk is bound by the round trip of a record's read, so kChunk records are requested
+            // together before any test looks at one.  Only what the first tests need is read here (the
+            // key where slabs are filtered, position and time): few records of a
+            // neighbourhood lie within the footprint, and those are queued for settle().
+            constexpr uint32_t kChunk = 4;
+            for (uint32_t base = lo[k]; base < hi[k]; base += kChunk)
             {
-                // The key and the whole 52-byte row are requested together, before any test looks at
-                // them: read field by field behind its test, a row costs up to five dependent round
-                // trips (key, position, time, normal, direction), and the loop is bound by exactly that.
-                typedef float Float4At4 __attribute__((ext_vector_type(4), aligned(4)));
-                const float* row = a.store + 13ull * j;
-                const unsigned long long key = a.keys[j];
-                Float4At4 q0 = *reinterpret_cast<const Float4At4*>(row);
-                Float4At4 q1 = *reinterpret_cast<const Float4At4*>(row + 4);
-                Float4At4 q2 = *reinterpret_cast<const Float4At4*>(row + 8);
-                float q3 = row[12];
-                asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3));  // the loads stay here, ahead of the branches
-                if (key > lastOfRow)
+                unsigned long long key[kChunk];
+                Float4At4 q0[kChunk];
+                float time[kChunk];
+#pragma unroll
+                for (uint32_t u = 0; u < kChunk; ++u)
                 {
-                    break;
+                    const uint32_t j = base + u < hi[k] ? base + u : hi[k] - 1;
+                    const float* row = a.store + 13ull * j;
+                    key[u] = bySlab ? a.keys[j] : 0ull;
+                    q0[u] = *reinterpret_cast<const Float4At4*>(row);
+                    time[u] = row[9];
                 }
-                if (bySlab)
+#pragma unroll
+                for (uint32_t u = 0; u < kChunk; ++u)
                 {
-                    const int64_t kx = static_cast<int64_t>(key & ((1ull << 21) - 1)) - kPackLimit;
-                    if (kx < x0 || kx > x1)
+                    asm volatile("" : "+v"(q0[u]), "+v"(time[u]));  // the reads stay ahead of the branches
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < kChunk; ++u)
+                {
+                    if (base + u >= hi[k])
                     {
                         continue;
                     }
-                }
-                const float rec[13] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3};
-                const double ddx = static_cast<double>(rec[0]) - position.x;
-                const double ddy = static_cast<double>(rec[1]) - position.y;
-                const double ddz = static_cast<double>(rec[2]) - position.z;
-                if (!(ddx * ddx + ddy * ddy + ddz * ddz <= r2))
-                {
-                    continue;
-                }
-                const float time = rec[9];
-                if (!__builtin_isinf(time) || time < 0.0f)  // +inf marks a timeless (emitter) deposit
-                {
-                    if (__builtin_fabsf(time - gp.sampleTime) > a.timeHalfWindow)
+                    if (bySlab)
+                    {
+                        const int64_t kx = static_cast<int64_t>(key[u] & ((1ull << 21) - 1)) - kPackLimit;
+                        if (kx < x0 || kx > x1)
+                        {
+                            continue;
+                        }
+                    }
+                    const double ddx = static_cast<double>(q0[u].x) - position.x;
+                    const double ddy = static_cast<double>(q0[u].y) - position.y;
+                    const double ddz = static_cast<double>(q0[u].z) - position.z;
+                    if (!(ddx * ddx + ddy * ddy + ddz * ddz <= r2))
                     {
                         continue;
                     }
-                }
-                const Vec dn = mk(rec[6], rec[7], rec[8]);
-                const Color power{rec[10], rec[11], rec[12]};
-                if (isEmitter)
-                {
-                    if (dot(dn, normal) < 0.5)
+                    if (!__builtin_isinf(time[u]) || time[u] < 0.0f)  // +inf marks a timeless (emitter) deposit
                     {
-                        continue;
+                        if (__builtin_fabsf(time[u] - gp.sampleTime) > a.timeHalfWindow)
+                        {
+                            continue;
+                        }
                     }
-                    sum.r += power.r;
-                    sum.g += power.g;
-                    sum.b += power.b;
-                    kept += 1;
-                    continue;
-                }
-                const double dnLen = magnitude(dn);
-                if (dnLen > 1e-4)
-                {
-                    if (dot(dn / dnLen, normal) < 0.5)
+                    queue[queued * kGatherThreads] = base + u;
+                    queued += 1;
+                    if (queued == kGatherQueue)
                     {
-                        continue;
+                        settle();
                     }
                 }
-                const double planeDist = dabs(dot(mk(rec[0], rec[1], rec[2]) - position, normal));
-                if (planeDist > planeBand)
-                {
-                    continue;
-                }
-                const Vec wi = neg(mk(rec[3], rec[4], rec[5]));
-                const Color f = evaluateMaterial(*material, wi, wo, normal);
-                const Color fp = f * power;
-                sum.r += fp.r;
-                sum.g += fp.g;
-                sum.b += fp.b;
-                kept += 1;
             }
         }
     }
+    settle();
     *deposits = kept;
     if (kept == 0)
     {
@@ -1534,10 +1737,12 @@ RT_DEV Color gatherRadiance(const GatherArgs& a, const GatherPoint& gp, unsigned
 // ProbeGather::run / gatherRecords, reference src/ProbeGather.cpp:865-994: one thread per
 // sampled pixel adds that pixel's records in their order, as the reference's single-threaded
 // loop does, then lands the sum in the camera buffer (Buffer::addColor, src/Buffer.cpp:22-37).
-__global__ __launch_bounds__(256) void gatherKernel(const GatherArgs a)
+__global__ __launch_bounds__(kGatherThreads) void gatherKernel(const GatherArgs a)
 {
+    __shared__ uint32_t queues[kGatherQueue * kGatherThreads];
     const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     unsigned long long added = 0, depositsAccum = 0;
+    bool heavy = false;
     if (i < a.pixels && a.counts[i] != 0)
     {
         const Camera& cam = a.scene.cameras[a.camera];
@@ -1551,7 +1756,11 @@ __global__ __launch_bounds__(256) void gatherKernel(const GatherArgs a)
                 continue;
             }
             unsigned long long deposits = 0;
-            const Color radiance = gatherRadiance(a, gp, &deposits);
+            const Color radiance = gatherRadiance(a, gp, queues + threadIdx.x, &deposits, &heavy);
+            if (heavy)
+            {
+                break;
+            }
             const Color throughput{gp.throughput[0], gp.throughput[1], gp.throughput[2]};
             const Color contribution = throughput * radiance * gp.sampleWeight;
             depositsAccum += deposits;
@@ -1566,7 +1775,13 @@ __global__ __launch_bounds__(256) void gatherKernel(const GatherArgs a)
         }
         const uint64_t w = static_cast<uint64_t>(cam.width), h = static_cast<uint64_t>(cam.height);
         const uint64_t at = ((static_cast<uint64_t>(points[0].py) * w) + static_cast<uint64_t>(points[0].px)) * 3;
-        if (added != 0 && at + 2 < w * h * 3)
+        if (heavy)
+        {
+            // the whole pixel is done again by a wave of its own: nothing of it is counted here
+            added = depositsAccum = 0;
+            a.heavyPixels[atomicAdd(a.heavyCount, 1ull)] = static_cast<uint32_t>(i);
+        }
+        else if (added != 0 && at + 2 < w * h * 3)
         {
             atomicAdd(cam.buffer + at + 0, acc.r);
             atomicAdd(cam.buffer + at + 1, acc.g);
@@ -1637,35 +1852,49 @@ RT_DEV Color gatherRadianceGroup(const GatherArgs& a, const GatherPoint& gp, int
     const int64_t rowCount = (z1 - z0 + 1) * rowsPerSlab;
     for (int64_t rowBase = 0; rowBase < rowCount; rowBase += G)
     {
-        uint64_t myStart = 0;
+        // records [myStart, myEnd) of the row this lane looks up (see gatherRadiance)
+        uint32_t myStart = 0, myEnd = 0;
         if (rowBase + member < rowCount)
         {
             const int64_t mine = rowBase + member;
-            myStart = lowerBound(a.keys, a.indexed, packCell(x0, y0 + mine % rowsPerSlab, z0 + mine / rowsPerSlab));
+            const int64_t y = y0 + mine % rowsPerSlab, z = z0 + mine / rowsPerSlab;
+            uint32_t from = 0, to = 0;
+            const bool listed = directoryEntries(a, x0, x1, y, bySlab ? y1 : y, z, &from, &to);
+            if (from < to)
+            {
+                myStart = listed ? a.cellStart[from] : 0u;
+                myEnd = listed ? a.cellStart[to] : static_cast<uint32_t>(a.indexed);
+                if (a.directoryKind != kDirectoryCells)
+                {
+                    const unsigned long long first = packCell(x0, y, z);
+                    const unsigned long long last = bySlab ? packCell(x1, y1, z) : packCell(x1, y, z);
+                    myStart += static_cast<uint32_t>(lowerBound(a.keys + myStart, myEnd - myStart, first));
+                    myEnd = myStart + static_cast<uint32_t>(lowerBound(a.keys + myStart, myEnd - myStart, last + 1));
+                }
+            }
         }
         const int rowsHere = static_cast<int>(rowCount - rowBase < G ? rowCount - rowBase : G);
         for (int t = 0; t < rowsHere; ++t)
         {
-            const int64_t row = rowBase + t;
-            const int64_t y = y0 + row % rowsPerSlab, z = z0 + row / rowsPerSlab;
-            const unsigned long long last = bySlab ? packCell(x1, y1, z) : packCell(x1, y, z);
-            const uint32_t startLo = G == 64 ? laneValue(static_cast<uint32_t>(myStart), t)
-                                             : __shfl(static_cast<uint32_t>(myStart), t, G);
-            const uint32_t startHi = G == 64 ? laneValue(static_cast<uint32_t>(myStart >> 32), t)
-                                             : __shfl(static_cast<uint32_t>(myStart >> 32), t, G);
-            for (uint64_t base = (static_cast<uint64_t>(startHi) << 32) | startLo;; base += G)
+            const uint32_t start = G == 64 ? laneValue(myStart, t) : __shfl(myStart, t, G);
+            const uint32_t end = G == 64 ? laneValue(myEnd, t) : __shfl(myEnd, t, G);
+            if (start >= end)
+            {
+                continue;  // the same for every lane of the group
+            }
+            for (uint64_t base = start;; base += G)
             {
                 typedef float Float4At4 __attribute__((ext_vector_type(4), aligned(4)));
                 const uint64_t j = base + static_cast<uint64_t>(member);
-                const bool inside = j < a.indexed;
-                const uint64_t at = inside ? j : a.indexed - 1;
+                const bool inside = j < end;
+                const uint64_t at = inside ? j : end - 1;
                 const float* row = a.store + 13ull * at;
-                const unsigned long long key = a.keys[at];
+                const unsigned long long key = bySlab ? a.keys[at] : 0ull;
                 const Float4At4 q0 = *reinterpret_cast<const Float4At4*>(row);
                 const Float4At4 q1 = *reinterpret_cast<const Float4At4*>(row + 4);
                 const Float4At4 q2 = *reinterpret_cast<const Float4At4*>(row + 8);
                 const float q3 = row[12];
-                const bool beyond = !inside || key > last;
+                const bool beyond = !inside;
                 bool passes = !beyond;
                 if (passes && bySlab)
                 {
@@ -1763,15 +1992,24 @@ template <int G>
 __global__ __launch_bounds__(256) void gatherGroupKernel(const GatherArgs a)
 {
     const int64_t thread = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    const int64_t i = thread / G;
     const int member = static_cast<int>(thread % G);
     const int groupBase = static_cast<int>(threadIdx.x & 63) - member;
     unsigned long long added = 0, depositsAccum = 0;
-    if (i < a.pixels && a.counts[i] != 0)
+    // all the pixels, a group each, or (second launch of the one-lane gather) the listed ones, which the
+    // grid's groups share out among themselves
+    const int64_t groups = static_cast<int64_t>(gridDim.x) * (blockDim.x / G);
+    const int64_t listed = a.pixelList != nullptr ? static_cast<int64_t>(*a.pixelListCount) : 0;
+    for (int64_t turn = thread / G; a.pixelList != nullptr ? turn < listed : turn == thread / G; turn += groups)
     {
+        const int64_t i = a.pixelList != nullptr ? static_cast<int64_t>(a.pixelList[turn]) : turn;
+        if (!(i < a.pixels && a.counts[i] != 0))
+        {
+            continue;
+        }
         const Camera& cam = a.scene.cameras[a.camera];
         const GatherPoint* points = a.points + a.offsets[i];
         Color acc{0.0f, 0.0f, 0.0f};
+        unsigned long long addedHere = 0;
         for (uint32_t k = 0; k < a.counts[i]; ++k)
         {
             const GatherPoint& gp = points[k];
@@ -1791,11 +2029,12 @@ __global__ __launch_bounds__(256) void gatherGroupKernel(const GatherArgs a)
             acc.r += contribution.r;
             acc.g += contribution.g;
             acc.b += contribution.b;
-            added += 1;
+            addedHere += 1;
         }
+        added += addedHere;
         const uint64_t w = static_cast<uint64_t>(cam.width), h = static_cast<uint64_t>(cam.height);
         const uint64_t at = ((static_cast<uint64_t>(points[0].py) * w) + static_cast<uint64_t>(points[0].px)) * 3;
-        if (member == 0 && added != 0 && at + 2 < w * h * 3)
+        if (member == 0 && addedHere != 0 && at + 2 < w * h * 3)
         {
             atomicAdd(cam.buffer + at + 0, acc.r);
             atomicAdd(cam.buffer + at + 1, acc.g);
@@ -2040,8 +2279,9 @@ void printDiagnostics()
     unsigned long long host[32] = {};
     if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_rtDiag), sizeof(host)) != hipSuccess) return;
 #if RT_DIAG == 2
-    const char* names[] = {"kernel", "casts", "node loops", "triangle loops", "refill", "deposit", "scatter"};
-    for (int k = 0; k < 7; ++k)
+    const char* names[] = {"kernel",       "casts",         "node loops",     "triangle loops", "refill",      "deposit",
+                           "scatter",      "cast: box",     "cast: pose",     "cast: normal",   "cast: world"};
+    for (int k = 0; k < 11; ++k)
     {
         fprintf(stderr, "[rt diag] wave cycles  %-15s %16llu  (%.1f %% of the kernel)\n", names[k], host[k],
                 host[0] ? 100.0 * static_cast<double>(host[k]) / static_cast<double>(host[0]) : 0.0);
@@ -2214,12 +2454,36 @@ void launchGatherWrite(const SceneView& scene, int32_t camera, int32_t stride, i
                        offsets, out);
 }
 
+hipError_t buildCellDirectory(void* scratch, size_t* scratchBytes, const unsigned long long* sortedKeys, uint64_t indexed,
+                              const int32_t cellMin[3], const int32_t cellDim[3], uint32_t* cellStart, hipStream_t stream)
+{
+    const size_t cells = static_cast<size_t>(cellDim[0]) * static_cast<size_t>(cellDim[1]) * static_cast<size_t>(cellDim[2]);
+    // an empty cell starts where the next cell with records does: a running minimum from the end
+    rocprim::reverse_iterator<uint32_t*> fromEnd(cellStart + cells + 1);
+    if (scratch == nullptr)
+    {
+        return rocprim::inclusive_scan(nullptr, *scratchBytes, fromEnd, fromEnd, cells + 1, rocprim::minimum<uint32_t>(), stream);
+    }
+    if (indexed == 0) return hipErrorInvalidValue;
+    const hipError_t status = hipMemsetAsync(cellStart, 0xFF, (cells + 1) * sizeof(uint32_t), stream);
+    if (status != hipSuccess) return status;
+    CellBox box;
+    for (int k = 0; k < 3; ++k)
+    {
+        box.low[k] = cellMin[k];
+        box.dim[k] = cellDim[k];
+    }
+    hipLaunchKernelGGL(cellFirstsKernel, dim3(gridFor(static_cast<int64_t>(indexed))), dim3(256), 0, stream, sortedKeys, indexed,
+                       box, cellStart);
+    return rocprim::inclusive_scan(scratch, *scratchBytes, fromEnd, fromEnd, cells + 1, rocprim::minimum<uint32_t>(), stream);
+}
+
 void launchStoreKeys(const float* store, uint64_t n, double invCellSize, unsigned long long* keys, uint32_t* order,
-                     hipStream_t stream)
+                     int32_t* cellBox, hipStream_t stream)
 {
     if (n == 0) return;
     hipLaunchKernelGGL(storeKeysKernel, dim3(gridFor(static_cast<int64_t>(n))), dim3(256), 0, stream, store, n,
-                       invCellSize, keys, order);
+                       invCellSize, keys, order, cellBox);
 }
 
 hipError_t sortStoreKeys(void* scratch, size_t* scratchBytes, const unsigned long long* keysIn,
@@ -2259,7 +2523,7 @@ void launchReorderStore(const float* store, const uint32_t* order, uint64_t inde
                        order, floats, sorted);
 }
 
-void launchGather(const GatherArgs& args, int lanesPerPixel, hipStream_t stream)
+void launchGather(const GatherArgs& args, int lanesPerPixel, int computeUnits, hipStream_t stream)
 {
     if (args.pixels <= 0) return;
     if (lanesPerPixel >= 64)
@@ -2272,7 +2536,17 @@ void launchGather(const GatherArgs& args, int lanesPerPixel, hipStream_t stream)
     }
     else
     {
-        hipLaunchKernelGGL(gatherKernel, dim3(gridFor(args.pixels)), dim3(256), 0, stream, args);
+        hipLaunchKernelGGL(gatherKernel, dim3(gridFor(args.pixels)), dim3(kGatherThreads), 0, stream, args);
+        if (args.heavyThreshold != 0)
+        {
+            // the pixels left over, a wave each: a grid that fills the chip takes them in turns
+            GatherArgs rest = args;
+            rest.heavyThreshold = 0;
+            rest.pixelList = args.heavyPixels;
+            rest.pixelListCount = args.heavyCount;
+            hipLaunchKernelGGL(gatherGroupKernel<64>, dim3(static_cast<uint32_t>(std::max(1, computeUnits) * 8)), dim3(256), 0, stream,
+                               rest);
+        }
     }
 }
 

@@ -7,7 +7,7 @@ for S in ${SCENES:-MirrorBombardment-200M CornellBox MirrorKnot4k CornellBoxGlas
   echo "== $S"; tail -2 $R/gpurun_out/prof_g_$S.log; python3 - "$F" <<'PY'
 import csv,sys
 rows=list(csv.DictReader(open(sys.argv[1])))
-for r in rows[:14]:
-    print(f"{r['Name'][:70]:70s} calls {r['Calls']:>5s} total_ms {float(r['TotalDurationNs'])/1e6:9.3f} avg_ms {float(r['AverageNs'])/1e6:9.3f}")
+for r in rows[:int(__import__("os").environ.get("TOP", "14"))]:
+    print(f"{r['Name'][:100]:100s} calls {r['Calls']:>5s} total_ms {float(r['TotalDurationNs'])/1e6:9.3f} avg_ms {float(r['AverageNs'])/1e6:9.3f}")
 PY
 done
