@@ -337,6 +337,7 @@ def main():
                 "photons_per_light": photons,
                 "lights": lights,
                 "sink": sink,
+                "scene_sink": "probe" if scene.settings.use_probe_gather else "splat",
                 "step": ("emitter deposits + photon pass + gather" if whole_frame and sink == "probe" else "photon pass")
                         + (" + all-reduce" if collective else ""),
                 "bounce_threshold": int(scene.settings.bounce_threshold),

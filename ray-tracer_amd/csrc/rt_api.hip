@@ -283,7 +283,10 @@ void buildScene(rt_tracer* t, const rt_scene* scene)
     std::vector<rtd::Node> nodes;
     std::vector<double> triRec, triNrm;
     std::vector<int32_t> triId;
-    int leafSize = 4;
+    // Triangles per leaf: a triangle test costs about two node steps, and with two a leaf a cast of
+    // the configurations' meshes tests a third fewer triangles for a step or two more (measured best on
+    // MirrorBombardment-200M and MirrorKnot4k; 1, 3, 4 and 6 were tried).
+    int leafSize = 2;
     if (const char* leaf = std::getenv("RT_AMD_LEAF"))
     {
         leafSize = std::atoi(leaf);
@@ -1701,6 +1704,9 @@ rtd::TraceArgs passArguments(const rt_tracer* tracer, const rt_trace_params* par
     args.totalWork = count * static_cast<uint64_t>(tracer->lightCount);
     args.minSplatRadius = tracer->minSplatRadius;
     args.sinkMode = params->sink_mode;
+    // (RT_AMD_SPLAT_TOGETHER=0: every lane adds its own splat, for measurements)
+    const char* together = std::getenv("RT_AMD_SPLAT_TOGETHER");
+    args.splatTogether = together == nullptr || std::atoi(together) != 0;
     return args;
 }
 

@@ -133,6 +133,7 @@ struct TraceArgs
     float keyOrigin[3];                       // corner of the scene's box and 1 / (its longest side)
     float keyScale;
     int32_t keyMode;                          // how the key is laid out (see rayKey)
+    int32_t splatTogether;                    // splat sink: lanes of a wave that hit one pixel add their sum once
 };
 
 hipError_t launchTrace(const TraceArgs& args, int blocks, hipStream_t stream);

@@ -411,8 +411,19 @@ RT_DEV void densityAdd(const DensityView& dv, const Vec& p, const Color& power, 
 // contributions are added up in lane order, and one lane issues the three atomics for all of them.  A
 // pixel only one lane adds to costs the ballots and nothing else.  Every lane of the wave that is
 // active at the call takes part; `emit` says whether it has something to add.
-RT_DEV void addToPixels(float* buffer, bool emit, uint32_t index, const Color& contribution)
+RT_DEV void addToPixels(float* buffer, bool emit, uint32_t index, const Color& contribution, bool together)
 {
+    if (!together)
+    {
+        // every lane for itself (kept for measurements of what adding together saves)
+        if (emit)
+        {
+            atomicAdd(buffer + index + 0, contribution.r);
+            atomicAdd(buffer + index + 1, contribution.g);
+            atomicAdd(buffer + index + 2, contribution.b);
+        }
+        return;
+    }
     unsigned long long pending = __ballot(emit);
     // A wave whose lanes all add to different pixels (a large image, photons deep in their paths) would
     // go round once per lane for nothing: after a few rounds the lanes still pending add on their own.
@@ -549,7 +560,7 @@ RT_DEV void splatToCamera(const TraceArgs& a, bool splats, const Vec& incoming, 
                 emit = true;
             } while (false);
         }
-        addToPixels(cam.buffer, emit, index, clamped);
+        addToPixels(cam.buffer, emit, index, clamped, a.splatTogether != 0);
     }
 }
 

@@ -17,7 +17,10 @@ def main(tag, rnd):
     bench = json.load(open(os.path.join(src, "bench.json")))
     workload, sink = bench["config"]["workload"], bench["config"]["sink"]
     photons = bench["config"]["photons_per_light"] * bench["config"]["lights"]
-    stem = os.path.join(dst, f"{rnd}_{workload}")
+    # a scene profiled with the sink that is not its own keeps both sets of files
+    own = bench["config"].get("scene_sink", sink)
+    name = workload if sink == own else f"{workload}_{sink}"
+    stem = os.path.join(dst, f"{rnd}_{name}")
     stats = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)[0]
     shutil.copy(stats, stem + "_kernel_stats.csv")
     shutil.copy(os.path.join(src, "stats_bench.json"), stem + "_kernel_stats_bench.json")
@@ -26,7 +29,7 @@ def main(tag, rnd):
     start = next(i for i, line in enumerate(lines) if line.startswith("kernel,counter,value"))
     with open(stem + "_pmc.csv", "w") as f:
         f.write("# rocprofv3 --pmc passes (one counter group per run, tools/profile.sh) of: python3 bench.py --scene "
-                f"scenes/{workload}.json --steps 1 --warmup 0 --no-cpu-baseline\n")
+                f"scenes/{workload}.json --sink {sink} --steps 1 --warmup 0 --no-cpu-baseline\n")
         f.write(f"# one step = one photon pass of {photons} photons ({sink} sink) and its gather; counters are summed over "
                 "a kernel's launches in the step; FETCH_SIZE / WRITE_SIZE are in KiB as rocprofv3 reports them, uncorrected\n")
         f.write("\n".join(lines[start:]) + "\n")
@@ -40,7 +43,7 @@ def main(tag, rnd):
     hits, misses = counters.get("TCC_HIT_sum", 0.0), counters.get("TCC_MISS_sum", 0.0)
     entry = {
         "workload": workload, "sink": sink, "photons_per_launch": photons, "trace_launches_per_pass": launches,
-        "source": f"profiles/{rnd}_{workload}_pmc.csv",
+        "source": f"profiles/{rnd}_{name}_pmc.csv",
         "SQ_ACTIVE_INST_VALU": counters["SQ_ACTIVE_INST_VALU"], "SQ_INSTS_VALU": counters["SQ_INSTS_VALU"],
         "SQ_INSTS_SALU": counters.get("SQ_INSTS_SALU"), "SQ_WAVE_CYCLES": counters.get("SQ_WAVE_CYCLES"),
         "SQ_BUSY_CYCLES": counters.get("SQ_BUSY_CYCLES"),
