@@ -96,7 +96,7 @@ int32_t rt_device_count(void);
  * triangles that returns the same closest hit (see rt_check_tree), flattens it, and
  * uploads volumes, materials, lights and cameras.  Stands in for the Worker wiring
  * block of Renderer::renderFrame (reference src/Renderer.cpp:421-459).
- * Environment: RT_AMD_LEAF=<1..16> triangles per leaf (default 4); RT_AMD_VERBOSE=1
+ * Environment: RT_AMD_LEAF=<1..16> triangles per leaf (default 2); RT_AMD_VERBOSE=1
  * prints each mesh's node count and depth. */
 int32_t rt_create(const rt_scene* scene, int32_t device, rt_tracer** out);
 void rt_destroy(rt_tracer* tracer);
