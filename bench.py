@@ -155,6 +155,9 @@ def main():
     ap.add_argument("--step", default="frame", choices=["frame", "pass"],
                     help="frame: emitter deposits, photon pass, gather, all-reduce; pass: the photon pass and the all-reduce")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--reuse-order", action="store_true",
+                    help="steps after the first reuse the pass's emission order (the frames of a sequence: same ids, "
+                         "same seed, same order); by default every step works it out anew, sort included")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend (nccl = RCCL; gloo only to rehearse the multi-rank path on one GPU)")
     ap.add_argument("--collective", default="auto", choices=["auto", "always"],
@@ -242,7 +245,7 @@ def main():
         if whole_frame and sink == "probe" and rank == 0:
             tracer.deposit_emitters(max(gather_cell * 0.5, 1e-6))
         if count > 0:  # an empty share traces nothing (a count of 0 would mean "all the rest")
-            tracer.trace(sink_mode=sink_mode, first_photon=first, photon_count=count)
+            tracer.trace(sink_mode=sink_mode, first_photon=first, photon_count=count, reuse_order=args.reuse_order)
         if whole_frame and sink == "probe":
             if timed:
                 tracer.synchronize()  # the gather waits for the pass anyway: this only separates the two times
@@ -338,6 +341,7 @@ def main():
                 "lights": lights,
                 "sink": sink,
                 "scene_sink": "probe" if scene.settings.use_probe_gather else "splat",
+                "emission_order": "reused from the step before" if args.reuse_order else "sorted anew every step",
                 "step": ("emitter deposits + photon pass + gather" if whole_frame and sink == "probe" else "photon pass")
                         + (" + all-reduce" if collective else ""),
                 "bounce_threshold": int(scene.settings.bounce_threshold),

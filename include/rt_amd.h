@@ -71,10 +71,15 @@ typedef struct rt_counters
     double deposited_power[3];        /* sum of photon power over all non-delta bounces */
 } rt_counters;
 
+/* rt_trace_params::flags.  RT_TRACE_REUSE_ORDER: the order in which the last pass took this very
+ * range of photons (a schedule computed from the seed and the ids, see rt_trace) may be used
+ * again instead of being worked out anew: for the frames of a sequence.  Results are the same. */
+#define RT_TRACE_REUSE_ORDER 1
+
 typedef struct rt_trace_params
 {
     int32_t sink_mode;       /* rt_sink_mode */
-    int32_t reserved;
+    int32_t flags;           /* RT_TRACE_... or 0 */
     uint64_t first_photon;   /* per light: trace photon indices [first, first+count)   */
     uint64_t photon_count;   /* 0 = settings.photons_per_light - first_photon           */
     uint64_t record_photons; /* keep per-bounce records of the first M photons traced   */

@@ -188,6 +188,15 @@ struct rt_tracer
 
     // sink A
     bool probesSet = false;
+    uint64_t probeVersion = 0;  // bumped whenever the probes are set anew
+    // The emitters' deposits of a frame depend on the probes, the patches and the spacing only: the
+    // records of one run are kept and copied into an empty store the next time.
+    struct EmitterDeposits
+    {
+        DeviceArray<float> records;
+        uint64_t kept = 0, samples = 0, probeVersion = 0;
+        double spacing = -1.0;
+    } emitterDeposits;
     DeviceArray<int64_t> slotKey;
     DeviceArray<uint32_t> slotStart, slotCount;
     DeviceArray<double> probePoints;
@@ -209,6 +218,7 @@ struct rt_tracer
     DeviceArray<rtd::DeviceCounters> counters;
     // emission-order list of a pass's photon ids
     DeviceArray<uint32_t> sortIds, sortOrder, sortKeysIn, sortKeysOut;
+    uint64_t orderedFirst = 0, orderedCount = 0;  // the range of photons per light sortOrder holds the order of (0: none)
     DeviceArray<rtd::PhotonState> photonQueue[2];
     // keys of the parked photons' rays, their sorted copy, the slot numbers in key order, 0..n-1
     DeviceArray<uint32_t> queueKeys, queueKeysSorted, queueOrder, queueIota;
@@ -1398,6 +1408,8 @@ void setProbes(rt_tracer* tracer, const double* probes, bool probesOnDevice, uin
     if (buildProbesOnDevice(tracer, probes, probesOnDevice, n, invCellSize, keepRadius))
     {
         tracer->probesSet = true;
+    tracer->probeVersion += 1;
+        tracer->probeVersion += 1;
         return;
     }
     // the general build works on the host
@@ -1466,6 +1478,7 @@ void setProbes(rt_tracer* tracer, const double* probes, bool probesOnDevice, uin
     tracer->packedCells.release();
     tracer->nearEntries.release();
     tracer->probesSet = true;
+    tracer->probeVersion += 1;
 }
 
 }  // namespace
@@ -1534,6 +1547,32 @@ int32_t rt_deposit_emitters(rt_tracer* tracer, double deposit_spacing, uint64_t*
         const double spacing = std::max(deposit_spacing, 1e-6);
         rtd::StoreView store{tracer->storeRecords.ptr, tracer->scalars.ptr + 1, tracer->storeCapacity};
         uint64_t sampleTotal = 0, keptTotal = 0;
+        // Into an empty store, with the probes and the spacing of the last run: the same records again
+        // (their order in the store is the schedule's, then as now).  (RT_AMD_EMITTER_CACHE=0: always anew)
+        rt_tracer::EmitterDeposits& last = tracer->emitterDeposits;
+        const char* cacheWanted = std::getenv("RT_AMD_EMITTER_CACHE");
+        const bool mayReuse = cacheWanted == nullptr || std::atoi(cacheWanted) != 0;
+        unsigned long long cursorBefore = 0;
+        check(hipMemcpyAsync(&cursorBefore, tracer->scalars.ptr + 1, sizeof(cursorBefore), hipMemcpyDeviceToHost, stream),
+              "hipMemcpyAsync cursor");
+        check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+        if (mayReuse && cursorBefore == 0 && last.spacing == spacing && last.probeVersion == tracer->probeVersion &&
+            last.kept <= tracer->storeCapacity)
+        {
+            if (last.kept > 0)
+            {
+                check(hipMemcpyAsync(tracer->storeRecords.ptr, last.records.ptr, last.kept * 13 * sizeof(float),
+                                     hipMemcpyDeviceToDevice, stream),
+                      "hipMemcpyAsync emitter deposits");
+                const unsigned long long cursor = last.kept;
+                check(hipMemcpyAsync(tracer->scalars.ptr + 1, &cursor, sizeof(cursor), hipMemcpyHostToDevice, stream),
+                      "hipMemcpyAsync cursor");
+                check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+            }
+            if (samples != nullptr) *samples = last.samples;
+            if (kept != nullptr) *kept = last.kept;
+            return;
+        }
         for (const rtd::EmitterPatch& patch : tracer->patchHost)
         {
             const double extentU = patch.isDisc ? patch.radius : patch.halfWidth;
@@ -1590,6 +1629,21 @@ int32_t rt_deposit_emitters(rt_tracer* tracer, double deposit_spacing, uint64_t*
             check(hipMemcpyAsync(&keptHere, scalars.ptr + 1, sizeof(keptHere), hipMemcpyDeviceToHost, stream), "hipMemcpyAsync");
             check(hipStreamSynchronize(stream), "hipStreamSynchronize");
             keptTotal += keptHere;
+        }
+        last.spacing = -1.0;
+        if (mayReuse && cursorBefore == 0 && keptTotal <= tracer->storeCapacity)
+        {
+            if (last.records.count < keptTotal * 13) last.records.allocate(std::max<uint64_t>(1, keptTotal * 13));
+            if (keptTotal > 0)
+            {
+                check(hipMemcpyAsync(last.records.ptr, tracer->storeRecords.ptr, keptTotal * 13 * sizeof(float),
+                                     hipMemcpyDeviceToDevice, stream),
+                      "hipMemcpyAsync emitter deposits");
+            }
+            last.kept = keptTotal;
+            last.samples = sampleTotal;
+            last.probeVersion = tracer->probeVersion;
+            last.spacing = spacing;
         }
         if (samples != nullptr) *samples = sampleTotal;
         if (kept != nullptr) *kept = keptTotal;
@@ -1797,18 +1851,29 @@ int32_t rt_trace(rt_tracer* tracer, const rt_trace_params* params)
                 tracer->sortIds.allocate(n);
                 tracer->sortKeysIn.allocate(n);
                 tracer->sortKeysOut.allocate(n);
+                tracer->orderedCount = 0;
             }
-            rtd::launchEmissionKeys(args, tracer->sortKeysIn.ptr, tracer->sortIds.ptr, tracer->stream);
-            const int lights = static_cast<int>(tracer->lightCount);
-            size_t bytes = 0;
-            check(rtd::sortEmissionPairs(nullptr, &bytes, tracer->sortKeysIn.ptr, tracer->sortKeysOut.ptr, tracer->sortIds.ptr,
-                                         tracer->sortOrder.ptr, n, lights, tracer->stream),
-                  "sort size query");
-            if (tracer->sortScratch.count < bytes) tracer->sortScratch.allocate(bytes);
-            check(rtd::sortEmissionPairs(tracer->sortScratch.ptr, &bytes, tracer->sortKeysIn.ptr, tracer->sortKeysOut.ptr,
-                                         tracer->sortIds.ptr, tracer->sortOrder.ptr, n, lights, tracer->stream),
-                  "emission sort");
-            check(hipGetLastError(), "emission sort");
+            // The order depends on the seed, the lights' kinds and the ids only, all fixed for a tracer: a
+            // caller that traces the same range again (the frames of a sequence) may ask for the list the
+            // last pass left (RT_TRACE_REUSE_ORDER).
+            const bool reuse = (params->flags & RT_TRACE_REUSE_ORDER) != 0 && tracer->orderedCount == args.photonCount &&
+                               tracer->orderedFirst == args.firstPhoton;
+            if (!reuse)
+            {
+                rtd::launchEmissionKeys(args, tracer->sortKeysIn.ptr, tracer->sortIds.ptr, tracer->stream);
+                const int lights = static_cast<int>(tracer->lightCount);
+                size_t bytes = 0;
+                check(rtd::sortEmissionPairs(nullptr, &bytes, tracer->sortKeysIn.ptr, tracer->sortKeysOut.ptr, tracer->sortIds.ptr,
+                                             tracer->sortOrder.ptr, n, lights, tracer->stream),
+                      "sort size query");
+                if (tracer->sortScratch.count < bytes) tracer->sortScratch.allocate(bytes);
+                check(rtd::sortEmissionPairs(tracer->sortScratch.ptr, &bytes, tracer->sortKeysIn.ptr, tracer->sortKeysOut.ptr,
+                                             tracer->sortIds.ptr, tracer->sortOrder.ptr, n, lights, tracer->stream),
+                      "emission sort");
+                check(hipGetLastError(), "emission sort");
+                tracer->orderedCount = args.photonCount;
+                tracer->orderedFirst = args.firstPhoton;
+            }
             args.emissionOrder = tracer->sortOrder.ptr;
         }
         check(hipEventRecord(tracer->stageEvents[1], tracer->stream), "hipEventRecord");

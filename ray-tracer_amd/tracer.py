@@ -23,9 +23,12 @@ class RtCounters(C.Structure):
     _fields_ = [(name, C.c_uint64) for name in COUNTER_FIELDS] + [("deposited_power", C.c_double * 3)]
 
 
+TRACE_REUSE_ORDER = 1  # rt_trace_params.flags
+
+
 class RtTraceParams(C.Structure):
     _fields_ = [
-        ("sink_mode", C.c_int32), ("reserved", C.c_int32), ("first_photon", C.c_uint64),
+        ("sink_mode", C.c_int32), ("flags", C.c_int32), ("first_photon", C.c_uint64),
         ("photon_count", C.c_uint64), ("record_photons", C.c_uint64),
     ]
 
@@ -185,8 +188,10 @@ class Tracer:
         _check(tracer_lib().rt_reset(self._handle))
 
     # -- the photon pass ----------------------------------------------------
-    def trace(self, sink_mode=SINK_NONE, first_photon=0, photon_count=0, record_photons=0):
-        params = RtTraceParams(sink_mode, 0, first_photon, photon_count, record_photons)
+    def trace(self, sink_mode=SINK_NONE, first_photon=0, photon_count=0, record_photons=0, reuse_order=False):
+        """reuse_order: the emission order of the last pass over the same range may be used again
+        (RT_TRACE_REUSE_ORDER): same results, no sort."""
+        params = RtTraceParams(sink_mode, TRACE_REUSE_ORDER if reuse_order else 0, first_photon, photon_count, record_photons)
         _check(tracer_lib().rt_trace(self._handle, C.byref(params)))
 
     def trace_static(self, sink_mode=SINK_NONE, first_photon=0, photon_count=0):

@@ -290,6 +290,21 @@ def test_sorted_pass_equals_oracle(rt, scene_opener, name, photons):
     assert np.array_equal(got["bounce_i32"], ref["bounce_i32"]), "ids"
     sort_ms, trace_ms = tracer.timings()
     assert sort_ms > 0.0 and trace_ms > 0.0
+    # the frames of a sequence may reuse the order: same results, no sort; another range sorts anew
+    tracer.reset()
+    tracer.trace(sink_mode=1)
+    sort_ms = tracer.timings()[0]  # with the work space in place
+    tracer.reset()
+    tracer.trace(sink_mode=1, record_photons=5000, reuse_order=True)
+    again = tracer.counters()
+    for k in ("photons", "casts", "bounces", "deposits", "kept", "culled", "store_size"):
+        assert again[k] == ref[k], k
+    assert_bits_equal(_sorted_records(tracer.store()), _sorted_records(ref["store"]), "store records, order reused")
+    assert_bits_equal(tracer.records()["bounce_f64"], ref["bounce_f64"], "hits, order reused")
+    assert tracer.timings()[0] < 0.5 * sort_ms
+    tracer.reset()
+    tracer.trace(sink_mode=1, first_photon=7, photon_count=photons - 7, reuse_order=True)
+    assert tracer.counters()["photons"] == (photons - 7) * scene.desc.light_count and tracer.timings()[0] > 0.5 * sort_ms
 
 
 PROBE_SCENES = {
@@ -377,6 +392,19 @@ def test_emitter_deposits_equal_oracle(rt, scene_opener, name):
     assert kept == len(want) and kept > 0 and samples == stats["generated"]
     assert tracer.counters()["store_size"] == kept
     assert_bits_equal(_sorted_records(tracer.store()), _sorted_records(np.asarray(want)), "emitter deposits")
+    # a second frame over the same probes gets the records the library kept from the first ...
+    tracer.reset()
+    assert tracer.deposit_emitters(setup["emitter_spacing"]) == (samples, kept)
+    assert tracer.counters()["store_size"] == kept
+    assert_bits_equal(_sorted_records(tracer.store()), _sorted_records(np.asarray(want)), "emitter deposits, kept copy")
+    # ... and deposits made into a store that already holds records are worked out anew and appended
+    assert tracer.deposit_emitters(setup["emitter_spacing"]) == (samples, kept)
+    assert tracer.counters()["store_size"] == 2 * kept
+    # new probes: nothing of the old run is reused
+    tracer.set_probes(setup["probes"][: max(1, len(setup["probes"]) // 2)], keep, keep, int(scene.settings.bounce_store_capacity))
+    tracer.reset()
+    half, _ = orc.deposit_emitters(setup["probes"][: max(1, len(setup["probes"]) // 2)], keep, keep, setup["emitter_spacing"])
+    assert tracer.deposit_emitters(setup["emitter_spacing"])[1] == len(half)
 
 
 def test_probe_keep_test_matches_store_decisions(rt, scene_opener):
