@@ -465,17 +465,25 @@ def test_gather_equals_oracle(rt, scene_opener, name, lanes, monkeypatch):
     want = {c: orc.gather(c, ref["store"], setup["gather_cell"], setup["min_gather_radius"]) for c in cameras}
 
     tracer.set_probes(tracer.collect_probe_positions(), keep, keep, setup["store_capacity"])
-    # (1) same store, same order
-    tracer.reset()
-    tracer.store_append(ref["store"])
-    for c in cameras:
-        stats = tracer.gather(c, setup["gather_cell"], setup["min_gather_radius"])
-        buffer, ostats = want[c]
-        assert stats["unindexed"] == 0
-        assert (stats["pixels_hit"], stats["pixels_gathered"], stats["deposits_accum"]) == (
-            ostats["pixels_hit"], ostats["pixels_gathered"], ostats["deposits_accum"])
-        assert ostats["pixels_gathered"] > 0
-        assert_bits_equal(tracer.camera_buffer(c), buffer, f"{name} camera {c} gathered buffer")
+    # (1) same store, same order — with every form of index over the sorted store: the directory of
+    # cells (what these small scenes get by themselves), a directory of rows of cells (large scenes:
+    # the rows are searched for the cells wanted) or none at all (the whole list is searched)
+    indexes = {"cells": {}, "rows": {"RT_AMD_GATHER_DIRECTORY": "3000"}, "none": {"RT_AMD_GATHER_DIRECTORY": "1"}}
+    for index, env in indexes.items():
+        monkeypatch.delenv("RT_AMD_GATHER_DIRECTORY", raising=False)
+        for key, value in env.items():
+            monkeypatch.setenv(key, value)
+        tracer.reset()
+        tracer.store_append(ref["store"])
+        for c in cameras:
+            stats = tracer.gather(c, setup["gather_cell"], setup["min_gather_radius"])
+            buffer, ostats = want[c]
+            assert stats["unindexed"] == 0
+            assert (stats["pixels_hit"], stats["pixels_gathered"], stats["deposits_accum"]) == (
+                ostats["pixels_hit"], ostats["pixels_gathered"], ostats["deposits_accum"]), index
+            assert ostats["pixels_gathered"] > 0
+            assert_bits_equal(tracer.camera_buffer(c), buffer, f"{name} camera {c} gathered buffer, index: {index}")
+    monkeypatch.delenv("RT_AMD_GATHER_DIRECTORY", raising=False)
     # (2) the device's own frame
     tracer.reset()
     tracer.store_append(emitters)
