@@ -751,11 +751,7 @@ RT_DEV bool castMesh(const SceneView& s, int32_t nodeBase, int32_t nodeCount, in
                 float leftBox[6], rightBox[6];
                 int32_t left, right;
                 const int32_t shared = __builtin_amdgcn_readfirstlane(cur);
-#ifdef RT_EXPERIMENT_LDS_UNIFORM
-                if (__ballot(cur != shared) == 0 && !(Cached && shared < ldsNodeCount))
-#else
                 if (__ballot(cur != shared) == 0)
-#endif
                 {
                     const auto node = uniformRead(nodes + shared);
 #pragma unroll
