@@ -192,6 +192,21 @@ uint64_t rt_trace_static_max_photons(void);
 int32_t rt_read_timings(rt_tracer* tracer, float* sort_ms, float* trace_ms);
 
 int32_t rt_read_counters(rt_tracer* tracer, rt_counters* out);
+
+/* ---- more than one GPU ----
+ * Photons shard by index range (rt_trace_params first_photon / photon_count), one tracer per GPU; what
+ * the reference's workers merge by writing into shared buffers (reference src/Renderer.cpp:421-582,
+ * src/Buffer.cpp:22-37) is merged here by an RCCL all-reduce.  rt_allreduce sums every camera buffer
+ * of the tracer over the ranks of `rccl_comm` (an ncclComm_t passed as void*; the caller made it, with
+ * ncclCommInitRank in a process per GPU or with rt_comm_init_all in one process), in place, on the
+ * tracer's stream, and waits; `totals` (optional) receives the counters summed over the ranks
+ * (deposited_power too; store_size is the sum of the ranks' stores).  Every rank calls it once per
+ * frame, after its gather.  RCCL (librccl.so) is loaded when first needed: RT_ERR_STATE if it cannot be. */
+int32_t rt_allreduce(rt_tracer* tracer, void* rccl_comm, rt_counters* totals);
+/* One process, n GPUs: ncclCommInitAll over `devices`; comms[i] belongs to devices[i] and is to be used
+ * from its own thread.  rt_comm_destroy releases one of them. */
+int32_t rt_comm_init_all(int32_t n, const int32_t* devices, void** comms);
+int32_t rt_comm_destroy(void* rccl_comm);
 /* Buffer::fetchColor over the whole image: rgb [h][w][3] (reference src/Buffer.cpp:39-53). */
 int32_t rt_read_camera_buffer(rt_tracer* tracer, int32_t camera, float* rgb);
 /* BounceStore records, 13 floats each (reference include/BounceStore.h:55-113):

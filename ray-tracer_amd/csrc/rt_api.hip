@@ -13,7 +13,9 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstddef>
 #include <cstring>
+#include <dlfcn.h>
 #include <limits>
 #include <map>
 #include <memory>
@@ -2113,6 +2115,111 @@ int32_t rt_read_counters(rt_tracer* tracer, rt_counters* out)
         {
             out->deposited_power[k] = dc.power[k];
         }
+    });
+}
+
+extern "C++"
+{
+namespace
+{
+
+// RCCL, loaded when a collective is first asked for (the library itself does not link it: a tracer on
+// one GPU needs none of it).  The three entry points used, by their C signatures (rccl.h).
+struct Rccl
+{
+    typedef int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t);
+    typedef int (*CommInitAll)(void**, int, const int*);
+    typedef int (*CommDestroy)(void*);
+    typedef const char* (*ErrorString)(int);
+    AllReduce allReduce = nullptr;
+    CommInitAll commInitAll = nullptr;
+    CommDestroy commDestroy = nullptr;
+    ErrorString errorString = nullptr;
+    static constexpr int kUint64 = 5, kFloat32 = 7, kFloat64 = 8, kSum = 0;  // ncclDataType_t, ncclRedOp_t
+};
+
+const Rccl& rccl()
+{
+    static Rccl lib;
+    static std::once_flag once;
+    std::call_once(once, []() {
+        void* handle = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (handle == nullptr) handle = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (handle == nullptr) return;
+        lib.allReduce = reinterpret_cast<Rccl::AllReduce>(dlsym(handle, "ncclAllReduce"));
+        lib.commInitAll = reinterpret_cast<Rccl::CommInitAll>(dlsym(handle, "ncclCommInitAll"));
+        lib.commDestroy = reinterpret_cast<Rccl::CommDestroy>(dlsym(handle, "ncclCommDestroy"));
+        lib.errorString = reinterpret_cast<Rccl::ErrorString>(dlsym(handle, "ncclGetErrorString"));
+    });
+    if (lib.allReduce == nullptr || lib.commInitAll == nullptr || lib.commDestroy == nullptr)
+    {
+        throw ApiError(RT_ERR_STATE, "RCCL (librccl.so) cannot be loaded");
+    }
+    return lib;
+}
+
+void checkRccl(int code, const char* what)
+{
+    if (code != 0)
+    {
+        const Rccl& lib = rccl();
+        throw ApiError(RT_ERR_DEVICE, std::string(what) + ": " + (lib.errorString ? lib.errorString(code) : "RCCL error"));
+    }
+}
+
+}  // namespace
+}  // extern "C++"
+
+int32_t rt_allreduce(rt_tracer* tracer, void* rccl_comm, rt_counters* totals)
+{
+    return guarded([&]() {
+        require(tracer != nullptr && rccl_comm != nullptr, "null argument");
+        const Rccl& lib = rccl();
+        activate(tracer);
+        for (const rtd::Camera& camera : tracer->cameraHost)
+        {
+            const size_t floats = static_cast<size_t>(camera.width) * static_cast<size_t>(camera.height) * 3;
+            if (floats == 0 || camera.buffer == nullptr) continue;
+            checkRccl(lib.allReduce(camera.buffer, camera.buffer, floats, Rccl::kFloat32, Rccl::kSum, rccl_comm, tracer->stream),
+                      "ncclAllReduce camera buffer");
+        }
+        if (totals != nullptr)
+        {
+            // the counters as rt_read_counters reports them, summed: fifteen integers and three doubles
+            rt_counters mine{};
+            const int32_t code = rt_read_counters(tracer, &mine);
+            if (code != RT_OK) throw ApiError(code, rt_last_error());
+            constexpr size_t kIntegers = offsetof(rt_counters, deposited_power) / sizeof(uint64_t);
+            static_assert(sizeof(rt_counters) == kIntegers * sizeof(uint64_t) + 3 * sizeof(double), "rt_counters layout");
+            DeviceArray<unsigned char> staged;
+            staged.allocate(sizeof(rt_counters));
+            check(hipMemcpyAsync(staged.ptr, &mine, sizeof(mine), hipMemcpyHostToDevice, tracer->stream), "hipMemcpyAsync counters");
+            checkRccl(lib.allReduce(staged.ptr, staged.ptr, kIntegers, Rccl::kUint64, Rccl::kSum, rccl_comm, tracer->stream),
+                      "ncclAllReduce counters");
+            unsigned char* powers = staged.ptr + kIntegers * sizeof(uint64_t);
+            checkRccl(lib.allReduce(powers, powers, 3, Rccl::kFloat64, Rccl::kSum, rccl_comm, tracer->stream),
+                      "ncclAllReduce deposited power");
+            check(hipMemcpyAsync(totals, staged.ptr, sizeof(*totals), hipMemcpyDeviceToHost, tracer->stream), "hipMemcpyAsync totals");
+        }
+        check(hipStreamSynchronize(tracer->stream), "hipStreamSynchronize");
+    });
+}
+
+int32_t rt_comm_init_all(int32_t n, const int32_t* devices, void** comms)
+{
+    return guarded([&]() {
+        require(n >= 1 && devices != nullptr && comms != nullptr, "bad arguments");
+        const Rccl& lib = rccl();
+        std::vector<int> list(devices, devices + n);
+        checkRccl(lib.commInitAll(comms, n, list.data()), "ncclCommInitAll");
+    });
+}
+
+int32_t rt_comm_destroy(void* rccl_comm)
+{
+    return guarded([&]() {
+        require(rccl_comm != nullptr, "null argument");
+        checkRccl(rccl().commDestroy(rccl_comm), "ncclCommDestroy");
     });
 }
 

@@ -5,11 +5,13 @@
 #include "rt_amd.h"
 
 #include <algorithm>
+#include <array>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cmath>
 #include <cstring>
+#include <functional>
 #include <future>
 #include <iostream>
 #include <limits>
@@ -38,6 +40,96 @@ struct TracerHandle
         if (ptr) rt_destroy(ptr);
     }
 };
+
+// The frame's photons over several GPUs of this machine: RT_AMD_DEVICES=<n> (at most the GPUs there
+// are; default 1).  RT_AMD_COLLECTIVE=1 takes the same path — communicator, all-reduce — with one GPU.
+int shardWorld()
+{
+    int wanted = 1;
+    if (const char* v = std::getenv("RT_AMD_DEVICES")) wanted = std::atoi(v);
+    return std::max(1, std::min(wanted, rt_device_count()));
+}
+
+struct Communicators
+{
+    std::vector<void*> comms;
+    ~Communicators()
+    {
+        for (void* c : comms)
+        {
+            if (c) rt_comm_destroy(c);
+        }
+    }
+};
+
+// photon indices [first, first + count) of rank `rank` among `world`
+void shardOf(size_t perLight, int rank, int world, size_t* first, size_t* count)
+{
+    *first = perLight * static_cast<size_t>(rank) / static_cast<size_t>(world);
+    *count = perLight * (static_cast<size_t>(rank) + 1) / static_cast<size_t>(world) - *first;
+}
+
+// What every rank but the first does for a frame, on its own GPU and thread: the same probe pass and
+// probe index (they are replicated), its share of the photons into its own store, its own gather into its
+// own camera buffers, then the all-reduce, which the first rank joins from renderFrame.  Emitter deposits
+// are the first rank's alone (a gather is linear in the records, so the sum of the ranks' images is the
+// image of the union of their stores).  Returns an error text, empty when all went well.
+std::string otherRankFrame(const rt_scene* scene, const FrameDerived& derived, int device, int rank, int world, void* comm,
+                           const std::vector<bool>& gathers)
+{
+    try
+    {
+        TracerHandle tracer;
+        check(rt_create(scene, device, &tracer.ptr));
+        const bool probeGather = scene->settings.use_probe_gather != 0;
+        if (probeGather)
+        {
+            for (size_t c = 0; c < gathers.size(); ++c)
+            {
+                if (!gathers[c]) continue;
+                uint64_t count = 0;
+                check(rt_collect_gather_points(tracer.ptr, static_cast<int32_t>(c), nullptr, 0, &count, nullptr));
+            }
+            uint64_t probeCount = 0, capacity = 0;
+            check(rt_set_probes_from_cameras(tracer.ptr, derived.keepRadius, derived.keepRadius, 256,
+                                             scene->settings.bounce_store_capacity, &probeCount, &capacity));
+        }
+        else
+        {
+            const uint64_t depositBound = static_cast<uint64_t>(scene->settings.photons_per_light) *
+                                          static_cast<uint64_t>(std::max<int64_t>(1, scene->light_count)) *
+                                          (static_cast<uint64_t>(std::max(0, scene->settings.bounce_threshold)) + 1);
+            check(rt_set_splat(tracer.ptr, derived.minSplatRadius, derived.cellSize,
+                               std::min<uint64_t>(1ull << 27, std::max<uint64_t>(1ull << 22, depositBound))));
+        }
+        check(rt_reset(tracer.ptr));
+        size_t first = 0, count = 0;
+        shardOf(static_cast<size_t>(scene->settings.photons_per_light), rank, world, &first, &count);
+        if (count > 0)
+        {
+            rt_trace_params params{};
+            params.sink_mode = probeGather ? RT_SINK_PROBE : RT_SINK_SPLAT;
+            params.first_photon = first;
+            params.photon_count = count;
+            check(rt_trace(tracer.ptr, &params));
+        }
+        if (probeGather)
+        {
+            const double gatherCell = derived.sceneDepthFootprint > 0.0 ? derived.sceneDepthFootprint : derived.cellSize;
+            for (size_t c = 0; c < gathers.size(); ++c)
+            {
+                if (!gathers[c]) continue;
+                check(rt_gather(tracer.ptr, static_cast<int32_t>(c), gatherCell, derived.minSplatRadius, nullptr));
+            }
+        }
+        check(rt_allreduce(tracer.ptr, comm, nullptr));
+        return std::string();
+    }
+    catch (const std::exception& failure)
+    {
+        return failure.what();
+    }
+}
 
 }  // namespace
 
@@ -125,15 +217,46 @@ RenderResult renderFrame(const LoadedScene& scene, ProgressCallback progress, Pr
             stageStart = now;
         }
     };
-    TracerHandle tracer;
-    check(rt_create(&flat.scene, g_device, &tracer.ptr));
-    stage("rt_create");
-
     std::vector<bool> debugCamera(cameras.size(), false);
     for (size_t c = 0; c < cameras.size(); ++c)
     {
         debugCamera[c] = cameras[c] && (cameras[c]->bounceFilter() >= 0 || cameras[c]->lightFilter() >= 0);
     }
+
+    // More than one GPU: this thread is rank 0 on the configured device, every other rank gets a
+    // thread and a GPU of its own (devices 0 .. n-1 but the configured one last-swapped in), and the
+    // frames meet in the all-reduce after the gather.
+    const int world = shardWorld();
+    const bool collective = world > 1 || (std::getenv("RT_AMD_COLLECTIVE") != nullptr && std::atoi(std::getenv("RT_AMD_COLLECTIVE")) != 0);
+    Communicators communicators;
+    std::vector<std::future<std::string>> otherRanks;
+    if (collective)
+    {
+        std::vector<int32_t> devices(static_cast<size_t>(world));
+        for (int r = 0; r < world; ++r)
+        {
+            devices[static_cast<size_t>(r)] = r;
+        }
+        if (g_device > 0 && g_device < world) std::swap(devices[0], devices[static_cast<size_t>(g_device)]);
+        else devices[0] = g_device;
+        communicators.comms.assign(static_cast<size_t>(world), nullptr);
+        check(rt_comm_init_all(world, devices.data(), communicators.comms.data()));
+        std::vector<bool> gathers(cameras.size(), false);
+        for (size_t c = 0; c < cameras.size(); ++c)
+        {
+            gathers[c] = cameras[c] && !debugCamera[c];
+        }
+        for (int r = 1; r < world; ++r)
+        {
+            otherRanks.push_back(std::async(std::launch::async, otherRankFrame, &flat.scene, std::cref(derived),
+                                            devices[static_cast<size_t>(r)], r, world, communicators.comms[static_cast<size_t>(r)],
+                                            gathers));
+        }
+        if (verbose) std::fprintf(stderr, "[rt_amd] %d GPU(s), frames summed by RCCL\n", world);
+    }
+    TracerHandle tracer;
+    check(rt_create(&flat.scene, g_device, &tracer.ptr));
+    stage("rt_create");
 
     double probeGatherMinRadius = 0.0;
     std::vector<ProbeGatherResult> probeStats(cameras.size());
@@ -189,7 +312,8 @@ RenderResult renderFrame(const LoadedScene& scene, ProgressCallback progress, Pr
     // to eight index ranges (the sinks add up over ranges) and the callback is asked between them, so
     // that returning false stops the frame early as it does in the reference's poll loop — a range
     // that has been launched runs to its end.
-    const size_t perLight = settings.photonsPerLight;
+    size_t shardFirst = 0, perLight = 0;  // this rank's share of the photons of every light
+    shardOf(settings.photonsPerLight, 0, world, &shardFirst, &perLight);
     const size_t totalWork = perLight * static_cast<size_t>(flat.scene.light_count);
     const size_t pieces = progress ? std::max<size_t>(1, std::min<size_t>(8, perLight / 1000000)) : 1;
     size_t traced = 0;
@@ -198,8 +322,8 @@ RenderResult renderFrame(const LoadedScene& scene, ProgressCallback progress, Pr
     {
         rt_trace_params params{};
         params.sink_mode = settings.useProbeGather ? RT_SINK_PROBE : RT_SINK_SPLAT;
-        params.first_photon = perLight * piece / pieces;
-        params.photon_count = perLight * (piece + 1) / pieces - params.first_photon;
+        params.first_photon = shardFirst + perLight * piece / pieces;
+        params.photon_count = shardFirst + perLight * (piece + 1) / pieces - params.first_photon;
         if (params.photon_count == 0)
         {
             continue;
@@ -239,6 +363,36 @@ RenderResult renderFrame(const LoadedScene& scene, ProgressCallback progress, Pr
     stage("photon pass (sort + trace)");
     result.photonPassSeconds =
         std::chrono::duration<double>(std::chrono::steady_clock::now() - photonPassStart).count();
+    // Several GPUs: every rank gathers its own store into its own buffers first, then the buffers and
+    // the counters are summed over the ranks; from here on this rank holds the whole frame.
+    const double gatherCell = derived.sceneDepthFootprint > 0.0 ? derived.sceneDepthFootprint : derived.cellSize;
+    std::vector<std::array<uint64_t, 4>> gatherStats(cameras.size(), std::array<uint64_t, 4>{0, 0, 0, 0});
+    std::vector<double> gatherSeconds(cameras.size(), 0.0);
+    std::vector<bool> gathered(cameras.size(), false);
+    if (collective)
+    {
+        for (size_t c = 0; c < cameras.size(); ++c)
+        {
+            if (cameras[c] && settings.useProbeGather && !debugCamera[c])
+            {
+                const auto gatherStart = std::chrono::steady_clock::now();
+                check(rt_gather(tracer.ptr, static_cast<int32_t>(c), gatherCell, probeGatherMinRadius, gatherStats[c].data()));
+                gatherSeconds[c] = std::chrono::duration<double>(std::chrono::steady_clock::now() - gatherStart).count();
+                gathered[c] = true;
+            }
+        }
+        stage("gather");
+        check(rt_allreduce(tracer.ptr, communicators.comms[0], &counters));
+        for (std::future<std::string>& other : otherRanks)
+        {
+            const std::string failure = other.get();
+            if (!failure.empty())
+            {
+                throw std::runtime_error("another GPU's share of the frame failed: " + failure);
+            }
+        }
+        stage("all-reduce");
+    }
     if (counters.density_dropped > 0)
     {
         std::cout << "Density grid: " << counters.density_dropped
@@ -266,7 +420,6 @@ RenderResult renderFrame(const LoadedScene& scene, ProgressCallback progress, Pr
 
     // ---- per camera: gather (probe mode) or the splat buffer, then tonemap (:670-790) ----
     const double photonsEmitted = static_cast<double>(settings.photonsPerLight);
-    const double gatherCell = derived.sceneDepthFootprint > 0.0 ? derived.sceneDepthFootprint : derived.cellSize;
     for (size_t c = 0; c < cameras.size(); ++c)
     {
         const std::shared_ptr<Camera>& cam = cameras[c];
@@ -281,13 +434,15 @@ RenderResult renderFrame(const LoadedScene& scene, ProgressCallback progress, Pr
         const auto gatherStart = std::chrono::steady_clock::now();
         if (settings.useProbeGather && !debugCamera[c])
         {
-            uint64_t stats[4] = {0, 0, 0, 0};
-            check(rt_gather(tracer.ptr, static_cast<int32_t>(c), gatherCell, probeGatherMinRadius, stats));
-            cr.probe.pixelsHit = stats[0];
-            cr.probe.pixelsGathered = stats[1];
-            cr.probe.depositsAccum = stats[2];
+            if (!gathered[c])
+            {
+                check(rt_gather(tracer.ptr, static_cast<int32_t>(c), gatherCell, probeGatherMinRadius, gatherStats[c].data()));
+            }
+            cr.probe.pixelsHit = gatherStats[c][0];
+            cr.probe.pixelsGathered = gatherStats[c][1];
+            cr.probe.depositsAccum = gatherStats[c][2];
         }
-        cr.gatherSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - gatherStart).count();
+        cr.gatherSeconds = gatherSeconds[c] + std::chrono::duration<double>(std::chrono::steady_clock::now() - gatherStart).count();
         stage("gather");
         cr.buffer = std::make_shared<Buffer>(cam->width(), cam->height());
         check(rt_read_camera_buffer(tracer.ptr, static_cast<int32_t>(c), cr.buffer->data()));

@@ -53,6 +53,9 @@ _SIGNATURES = {
     "rt_trace_static": (C.c_int32, [C.c_void_p, C.POINTER(RtTraceParams)]),
     "rt_trace_static_max_photons": (C.c_uint64, []),
     "rt_synchronize": (C.c_int32, [C.c_void_p]),
+    "rt_allreduce": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rt_comm_init_all": (C.c_int32, [C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_void_p)]),
+    "rt_comm_destroy": (C.c_int32, [C.c_void_p]),
     "rt_read_timings": (C.c_int32, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "rt_read_counters": (C.c_int32, [C.c_void_p, C.POINTER(RtCounters)]),
     "rt_read_camera_buffer": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p]),
@@ -119,6 +122,19 @@ def _check(code):
 
 def _ptr(a):
     return a.ctypes.data_as(C.c_void_p)
+
+
+def comm_init_all(devices):
+    """One RCCL communicator per listed device, made in this process (rt_comm_init_all)."""
+    n = len(devices)
+    ids = (C.c_int32 * n)(*devices)
+    comms = (C.c_void_p * n)()
+    _check(tracer_lib().rt_comm_init_all(n, ids, comms))
+    return [C.c_void_p(c) for c in comms]
+
+
+def comm_destroy(comm):
+    _check(tracer_lib().rt_comm_destroy(comm))
 
 
 def rows(fn_name, inputs, out_cols, out_dtype=np.float64, device=0):
@@ -213,6 +229,15 @@ class Tracer:
     def counters(self):
         c = RtCounters()
         _check(tracer_lib().rt_read_counters(self._handle, C.byref(c)))
+        out = {name: int(getattr(c, name)) for name in COUNTER_FIELDS}
+        out["deposited_power"] = np.array(list(c.deposited_power))
+        return out
+
+    def allreduce(self, comm):
+        """Sum the camera buffers over the ranks of an RCCL communicator (see comm_init_all); returns
+        the counters summed over the ranks."""
+        c = RtCounters()
+        _check(tracer_lib().rt_allreduce(self._handle, comm, C.byref(c)))
         out = {name: int(getattr(c, name)) for name in COUNTER_FIELDS}
         out["deposited_power"] = np.array(list(c.deposited_power))
         return out

@@ -119,6 +119,36 @@ def test_cli_renders_frame_equal_to_oracle(rt, tmp_path, probe_gather):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("probe_gather", [True, False])
+def test_cli_frame_through_the_collective_path(tmp_path, probe_gather):
+    """RT_AMD_COLLECTIVE=1 takes the several-GPU path of renderFrame with the one GPU there is: an RCCL
+    communicator, the gather of every camera before the all-reduce of buffers and counters.  With one
+    rank the frame must be the frame of the plain path: same counters in the report, same buffers."""
+    scene = json.load(open(os.path.join(REPO, "tests", "scenes", "mixed.json")))
+    scene["$renderConfiguration"].update({"$photonsPerLight": 3000, "$renderName": "mixed", "$probeGather": probe_gather,
+                                          "$probeKeepRadiusScale": 2.0})
+    outputs = {}
+    for mode in ("plain", "collective"):
+        scene["$renderConfiguration"]["$renderPath"] = str(tmp_path / mode)
+        path = tmp_path / f"{mode}.json"
+        path.write_text(json.dumps(scene))
+        env = dict(os.environ, RT_DUMP_BUFFERS=str(tmp_path / mode / "dump"))
+        if mode == "collective":
+            env["RT_AMD_COLLECTIVE"] = "1"
+        r = run_cli(str(path), env=env)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        report = [line for line in r.stdout.splitlines() if line.startswith(("Photon pass:", "Probe gather: kept"))]
+        buffers = sorted((tmp_path / mode / "dump").glob("camera*.f32"))
+        assert report and buffers
+        outputs[mode] = ([line.split(" seconds=")[0] for line in report], [np.fromfile(b, dtype=np.float32) for b in buffers])
+    assert outputs["plain"][0] == outputs["collective"][0]
+    for a, b in zip(outputs["plain"][1], outputs["collective"][1]):
+        assert a.any()
+        # float sums in the order of the run (the store's append order, the splat sink's atomics)
+        np.testing.assert_allclose(a, b, rtol=2e-4, atol=1e-6 * float(np.abs(a).max()))
+
+
+@pytest.mark.gpu
 def test_cli_renders_keyframed_frames(rt, tmp_path):
     """$animation end to end: two frames of the keyframed scene (frame / frameRate is the frame
     time, reference src/main.cpp:95-100), each equal to the oracle's frame at that time, and

@@ -708,6 +708,27 @@ def test_high_photon_indices_equal_oracle(rt, scene_opener, name):
     assert np.array_equal(got["bounce_power"], ref["bounce_power"]), "power"
 
 
+def test_collective_entry_point_with_one_rank(rt, scene_opener, tracer_mod):
+    """rt_allreduce over a communicator of this one GPU: RCCL loads, the all-reduce runs on the
+    tracer's stream over the camera buffers and the counters, and with one rank changes nothing."""
+    scene, tracer, orc = _open(rt, scene_opener, dict(SCENES["multicam"], photons_per_light=20000))
+    tracer.set_splat(0.05)
+    tracer.reset()
+    tracer.trace(sink_mode=2)
+    before = [tracer.camera_buffer(c).copy() for c in range(scene.desc.camera_count)]
+    mine = tracer.counters()
+    assert mine["splat_total"] > 0 and any(b.any() for b in before)
+    (comm,) = tracer_mod.comm_init_all([0])
+    try:
+        totals = tracer.allreduce(comm)
+    finally:
+        tracer_mod.comm_destroy(comm)
+    for name, value in mine.items():
+        assert np.array_equal(totals[name], value), name
+    for c, b in enumerate(before):
+        assert_bits_equal(tracer.camera_buffer(c), b, f"camera {c} after a one-rank all-reduce")
+
+
 def test_empty_inputs(rt, scene_opener):
     """Nothing to trace, nothing to hit, nothing to keep: no crash, no hang, the obvious counters."""
     entry = dict(SCENES["mixed"], photons_per_light=2000)
