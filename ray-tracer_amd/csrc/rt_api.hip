@@ -2556,7 +2556,7 @@ int32_t rt_gather(rt_tracer* tracer, int32_t camera, double gather_cell_size, do
             // camera pixels over a densely lit surface get a wave each, a 4K frame over a thin store
             // keeps one lane per pixel.  (RT_AMD_GATHER_LANES=1|8|64 overrides, for measurements.)
             const uint64_t perPoint = indexed / std::max<uint64_t>(1, cache.total);
-            int lanes = perPoint >= 64 ? 64 : (perPoint >= 3 ? 8 : 1);
+            int lanes = perPoint >= 64 ? 64 : (perPoint >= 8 ? 8 : 1);
             if (const char* v = std::getenv("RT_AMD_GATHER_LANES")) lanes = std::atoi(v);
             // One lane per pixel, with the directory: a pixel that looks at a crowded spot (an emitter's
             // deposits, a caustic) is handed to a wave of its own instead of holding up its wave.

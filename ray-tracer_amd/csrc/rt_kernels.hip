@@ -1675,7 +1675,7 @@ RT_DEV Color gatherRadiance(const GatherArgs& a, const GatherPoint& gp, uint32_t
             // together before any test looks at one.  Only what the first tests need is read here (the
             // key where slabs are filtered, position and time): few records of a
             // neighbourhood lie within the footprint, and those are queued for settle().
-            constexpr uint32_t kChunk = 4;
+            constexpr uint32_t kChunk = 8;
             for (uint32_t base = lo[k]; base < hi[k]; base += kChunk)
             {
                 unsigned long long key[kChunk];
