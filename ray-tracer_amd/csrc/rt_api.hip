@@ -2552,16 +2552,18 @@ int32_t rt_gather(rt_tracer* tracer, int32_t camera, double gather_cell_size, do
         }
         if (cache.total > 0)
         {
-            // Lanes per sampled pixel, by how many records a gather point meets on average: a few
-            // camera pixels over a densely lit surface get a wave each, a 4K frame over a thin store
-            // keeps one lane per pixel.  (RT_AMD_GATHER_LANES=1|8|64 overrides, for measurements.)
-            const uint64_t perPoint = indexed / std::max<uint64_t>(1, cache.total);
-            int lanes = perPoint >= 64 ? 64 : (perPoint >= 8 ? 8 : 1);
+            // One lane per sampled pixel looks up the pixel's rows; a pixel with more records in them than a
+            // limit is handed to a wave of its own in a second launch.  Up to a few million gather points
+            // the limit is one record — the first launch only sorts out the pixels with nothing to add, and
+            // waves do the gathering, 64 records at a time —; a 4K frame has more pixels than that pays for,
+            // and each of its pixels few records: there a lane keeps its pixel unless it looks at a crowded
+            // spot (an emitter's deposits, a caustic).
+            // (RT_AMD_GATHER_HEAVY=<records> sets the limit, 0 turns the hand-over off;
+            // RT_AMD_GATHER_LANES=1|8|64 forces one launch with that many lanes per pixel, handing over
+            // under the limit when it is 1: for measurements and tests.)
+            int lanes = 1;
+            uint32_t heavy = cache.total <= (4u << 20) ? 1u : 256u;
             if (const char* v = std::getenv("RT_AMD_GATHER_LANES")) lanes = std::atoi(v);
-            // One lane per pixel, with the directory: a pixel that looks at a crowded spot (an emitter's
-            // deposits, a caustic) is handed to a wave of its own instead of holding up its wave.
-            // (RT_AMD_GATHER_HEAVY=<records> sets the limit, 0 turns the hand-over off)
-            uint32_t heavy = 256;
             if (const char* v = std::getenv("RT_AMD_GATHER_HEAVY")) heavy = static_cast<uint32_t>(std::strtoul(v, nullptr, 10));
             if (lanes < 8 && heavy != 0 && cache.pixels < (1ll << 32))
             {

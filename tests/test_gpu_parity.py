@@ -439,11 +439,12 @@ GATHER_SCENES = {
 }
 
 
-@pytest.mark.parametrize("lanes", [0, 1, 8, 64])
+@pytest.mark.parametrize("lanes,hand_over", [(0, None), (1, 0), (1, 3), (8, None), (64, None)])
 @pytest.mark.parametrize("name", sorted(GATHER_SCENES))
-def test_gather_equals_oracle(rt, scene_opener, name, lanes, monkeypatch):
-    """(The gather gives a sampled pixel 1, 8 or 64 lanes by how dense the store is: 0 lets it choose, the
-    other values force each form; the result may not depend on it by a single bit.)
+def test_gather_equals_oracle(rt, scene_opener, name, lanes, hand_over, monkeypatch):
+    """(The gather gives a sampled pixel a lane and hands it to a wave when it meets more records than a
+    limit: (0, None) is its own choice, (1, 0) keeps every pixel in its lane, (1, 3) mixes both, 8 and 64 force
+    that many lanes per pixel in one launch; the result may not depend on it by a single bit.)
     The whole probe-mode frame after the photon pass.  (1) Given the SAME store, record for
     record in the same order, the device gather (sort by cell, one thread per pixel) returns
     the oracle's camera buffers bit for bit.  (2) The device's own frame (emitter deposits
@@ -452,6 +453,8 @@ def test_gather_equals_oracle(rt, scene_opener, name, lanes, monkeypatch):
     on append order the same way when it runs more than one worker)."""
     if lanes:
         monkeypatch.setenv("RT_AMD_GATHER_LANES", str(lanes))
+    if hand_over is not None:
+        monkeypatch.setenv("RT_AMD_GATHER_HEAVY", str(hand_over))
     scene, tracer, orc = _open(rt, scene_opener, GATHER_SCENES[name])
     setup = O.frame_setup(orc, O.RNG_COUNTER, O.MATH_PORTABLE)
     keep = setup["keep_radius"]
