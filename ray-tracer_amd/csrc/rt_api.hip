@@ -266,6 +266,8 @@ struct rt_tracer
         DeviceArray<unsigned char> directoryScratch;
         DeviceArray<uint32_t> heavyPixels;  // pixels the one-lane gather leaves to a wave each
         int32_t cellMin[3] = {0, 0, 0}, cellDim[3] = {0, 0, 0};
+        int32_t box[6] = {0, 0, 0, -1, -1, -1};  // least and greatest cell of the records that pack
+        rtd::KeyLayout layout{};
         int32_t directoryKind = 0;  // rtd::kDirectory...
         // the index these arrays hold: valid while the store has not changed since (storeVersion)
         uint64_t indexedVersion = 0, indexedRecords = 0, indexed = 0;
@@ -2445,17 +2447,23 @@ int32_t rt_gather(rt_tracer* tracer, int32_t camera, double gather_cell_size, do
                 orderIn.allocate(n);
                 orderOut.allocate(n);
             }
+            // the box of the records' cells first: the keys are relative to it and as wide as it needs
             if (g.cellBox.count == 0) g.cellBox.allocate(6);
             const int32_t emptyBox[6] = {INT32_MAX, INT32_MAX, INT32_MAX, INT32_MIN, INT32_MIN, INT32_MIN};
             check(hipMemcpy(g.cellBox.ptr, emptyBox, sizeof(emptyBox), hipMemcpyHostToDevice), "hipMemcpy cell box");
-            rtd::launchStoreKeys(tracer->storeRecords.ptr, n, 1.0 / cellSize, keysIn.ptr, orderIn.ptr, g.cellBox.ptr,
-                                 tracer->stream);
+            rtd::launchStoreBox(tracer->storeRecords.ptr, n, 1.0 / cellSize, g.cellBox.ptr, tracer->stream);
+            check(hipGetLastError(), "store box launch");
+            check(hipMemcpyAsync(g.box, g.cellBox.ptr, sizeof(g.box), hipMemcpyDeviceToHost, tracer->stream), "hipMemcpyAsync cell box");
+            check(hipStreamSynchronize(tracer->stream), "hipStreamSynchronize");
+            g.layout = rtd::keyLayoutFor(g.box);
+            rtd::launchStoreKeys(tracer->storeRecords.ptr, n, 1.0 / cellSize, g.layout, keysIn.ptr, orderIn.ptr, tracer->stream);
             check(hipGetLastError(), "store keys launch");
             size_t bytes = 0;
-            check(rtd::sortStoreKeys(nullptr, &bytes, keysIn.ptr, keysOut.ptr, orderIn.ptr, orderOut.ptr, n, tracer->stream),
+            check(rtd::sortStoreKeys(nullptr, &bytes, keysIn.ptr, keysOut.ptr, orderIn.ptr, orderOut.ptr, n, g.layout.bits,
+                                     tracer->stream),
                   "sort size query");
             if (scratch.count < bytes) scratch.allocate(bytes > 0 ? bytes : 1);
-            check(rtd::sortStoreKeys(scratch.ptr, &bytes, keysIn.ptr, keysOut.ptr, orderIn.ptr, orderOut.ptr, n,
+            check(rtd::sortStoreKeys(scratch.ptr, &bytes, keysIn.ptr, keysOut.ptr, orderIn.ptr, orderOut.ptr, n, g.layout.bits,
                                      tracer->stream),
                   "store sort");
             check(hipGetLastError(), "store sort");
@@ -2477,8 +2485,7 @@ int32_t rt_gather(rt_tracer* tracer, int32_t camera, double gather_cell_size, do
                 // than the limit (small cells in a large scene) gets a directory of its rows of cells
                 // instead, within which the gather searches; one with more rows than that goes without.
                 // (RT_AMD_GATHER_DIRECTORY=0 turns it off, any other number is the limit in entries)
-                int32_t box[6];
-                check(hipMemcpy(box, g.cellBox.ptr, sizeof(box), hipMemcpyDeviceToHost), "hipMemcpy cell box");
+                const int32_t* box = g.box;
                 uint64_t limit = 1ull << 27;
                 if (const char* v = std::getenv("RT_AMD_GATHER_DIRECTORY")) limit = std::strtoull(v, nullptr, 10);
                 uint64_t cells = 0;
@@ -2512,11 +2519,11 @@ int32_t rt_gather(rt_tracer* tracer, int32_t camera, double gather_cell_size, do
                 {
                     if (g.cellStart.count < cells + 1) g.cellStart.allocate(cells + 1);
                     size_t directoryBytes = 0;
-                    check(rtd::buildCellDirectory(nullptr, &directoryBytes, keysOut.ptr, indexed, g.cellMin, g.cellDim,
+                    check(rtd::buildCellDirectory(nullptr, &directoryBytes, keysOut.ptr, indexed, g.layout, g.cellMin, g.cellDim,
                                                   g.cellStart.ptr, tracer->stream),
                           "directory size query");
                     if (g.directoryScratch.count < directoryBytes) g.directoryScratch.allocate(directoryBytes > 0 ? directoryBytes : 1);
-                    check(rtd::buildCellDirectory(g.directoryScratch.ptr, &directoryBytes, keysOut.ptr, indexed, g.cellMin,
+                    check(rtd::buildCellDirectory(g.directoryScratch.ptr, &directoryBytes, keysOut.ptr, indexed, g.layout, g.cellMin,
                                                   g.cellDim, g.cellStart.ptr, tracer->stream),
                           "cell directory");
                     check(hipGetLastError(), "cell directory");
@@ -2533,6 +2540,7 @@ int32_t rt_gather(rt_tracer* tracer, int32_t camera, double gather_cell_size, do
         args.scene = tracer->view;
         args.store = sortedStore.ptr;
         args.keys = keysOut.ptr;
+        args.layout = g.layout;
         args.indexed = indexed;
         args.invCellSize = 1.0 / cellSize;
         args.minGatherRadius = min_gather_radius;

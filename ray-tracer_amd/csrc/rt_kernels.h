@@ -176,11 +176,21 @@ enum : int32_t
     kDirectoryRows = 2
 };
 
+// How a record's cell becomes its key: the cell relative to the least cell of the store's box, x in the
+// lowest bitsX bits, y in the next bitsY, z above (as many bits as the box needs: the radix sort runs a
+// pass per 8 of them).  No valid key has all bits of its z part set, so kEmptyKey's low bits sort last.
+struct KeyLayout
+{
+    int32_t low[3], high[3];  // least and greatest cell of the box
+    int32_t bitsX, bitsY, bits;  // bits = all three parts together
+};
+
 struct GatherArgs
 {
     SceneView scene;
     const float* store;                 // [records][13], IN KEY ORDER (launchReorderStore): row j belongs to keys[j]
-    const unsigned long long* keys;     // packed cell of each record, ascending
+    const unsigned long long* keys;     // key of each record (see KeyLayout), ascending
+    KeyLayout layout;
     uint64_t indexed;                   // records that carry a valid key
     double invCellSize;
     double minGatherRadius;
@@ -210,16 +220,20 @@ struct GatherArgs
     const uint32_t* pixelList;
     const unsigned long long* pixelListCount;
 };
-// cellBox (may be null): [0..2] least and [3..5] greatest x, y, z of the cells that pack, to be
-// preset to INT32_MAX / INT32_MIN
-void launchStoreKeys(const float* store, uint64_t n, double invCellSize, unsigned long long* keys, uint32_t* order,
-                     int32_t* cellBox, hipStream_t stream);
+// cellBox: [0..2] least and [3..5] greatest x, y, z of the records' cells that pack, to be preset to
+// INT32_MAX / INT32_MIN
+void launchStoreBox(const float* store, uint64_t n, double invCellSize, int32_t* cellBox, hipStream_t stream);
+// The layout of the keys for a box (empty box: any layout will do, there is no key to make)
+KeyLayout keyLayoutFor(const int32_t box[6]);
+void launchStoreKeys(const float* store, uint64_t n, double invCellSize, const KeyLayout& layout, unsigned long long* keys,
+                     uint32_t* order, hipStream_t stream);
 // The directory GatherArgs::cellStart describes, from the sorted keys: `cells` + 1 entries.
 hipError_t buildCellDirectory(void* scratch, size_t* scratchBytes, const unsigned long long* sortedKeys, uint64_t indexed,
-                              const int32_t cellMin[3], const int32_t cellDim[3], uint32_t* cellStart, hipStream_t stream);
-// Stable ascending sort of (keys, order).
+                              const KeyLayout& layout, const int32_t cellMin[3], const int32_t cellDim[3], uint32_t* cellStart,
+                              hipStream_t stream);
+// Stable ascending sort of (keys, order) over the lowest `bits` bits of the keys.
 hipError_t sortStoreKeys(void* scratch, size_t* scratchBytes, const unsigned long long* keysIn,
-                         unsigned long long* keysOut, const uint32_t* orderIn, uint32_t* orderOut, uint64_t n,
+                         unsigned long long* keysOut, const uint32_t* orderIn, uint32_t* orderOut, uint64_t n, int bits,
                          hipStream_t stream);
 // out[0] = number of leading keys below the "no cell" key (records of unpackable cells sort to the end)
 void launchCountIndexed(const unsigned long long* sortedKeys, uint64_t n, unsigned long long* out, hipStream_t stream);

@@ -1294,38 +1294,55 @@ __global__ void probeTestKernel(const ProbeView pv, int64_t n, const double* poi
 // cell of its float position; here the key packs the three cell coordinates, z in the
 // high bits, so that ascending key order IS the dz / dy / dx order in which
 // BounceStore::radiusSearch (:55-98) walks the cells, and a stable sort keeps the records
-// of one cell in store order.  A record whose cell does not fit 21 bits per axis gets
-// kEmptyKey and is left out of the index.
-RT_DEV unsigned long long packCell(int64_t x, int64_t y, int64_t z)
+// of one cell in store order.  The coordinates are taken relative to the box of the store's cells and
+// packed without gaps (KeyLayout): the sort then runs over the bits the box needs, not over 63.  A record
+// whose cell lies beyond +-2^20 cells gets kEmptyKey and is left out of the index.
+RT_DEV unsigned long long cellKey(const KeyLayout& l, int64_t x, int64_t y, int64_t z)  // a cell of the box
 {
-    return (static_cast<unsigned long long>(z + kPackLimit) << 42) | (static_cast<unsigned long long>(y + kPackLimit) << 21) |
-           static_cast<unsigned long long>(x + kPackLimit);
+    return (static_cast<unsigned long long>(z - l.low[2]) << (l.bitsX + l.bitsY)) |
+           (static_cast<unsigned long long>(y - l.low[1]) << l.bitsX) | static_cast<unsigned long long>(x - l.low[0]);
 }
 
-__global__ void storeKeysKernel(const float* store, uint64_t n, double invCellSize, unsigned long long* keys,
-                                uint32_t* order, int32_t* cellBox)
+RT_DEV int64_t keyCellX(const KeyLayout& l, unsigned long long key)
 {
-    const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    int32_t low[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, high[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
-    if (i < n)
+    return static_cast<int64_t>(key & ((1ull << l.bitsX) - 1)) + l.low[0];
+}
+
+RT_DEV bool recordCell(const float* r, double invCellSize, int64_t* x, int64_t* y, int64_t* z)
+{
+    *x = static_cast<int64_t>(__builtin_floor(static_cast<double>(r[0]) * invCellSize));
+    *y = static_cast<int64_t>(__builtin_floor(static_cast<double>(r[1]) * invCellSize));
+    *z = static_cast<int64_t>(__builtin_floor(static_cast<double>(r[2]) * invCellSize));
+    return *x >= -kPackLimit && *x < kPackLimit && *y >= -kPackLimit && *y < kPackLimit && *z >= -kPackLimit && *z < kPackLimit;
+}
+
+// The box of the records' cells: every thread takes a few records, a block reduces in LDS and one
+// thread asks for the atomics, and only where the block widens what it reads in the box (the box settles
+// after a few blocks; unconditional atomics would queue the whole launch up at six words).
+__global__ __launch_bounds__(256) void storeBoxKernel(const float* store, uint64_t n, double invCellSize, int32_t* cellBox)
+{
+    __shared__ int32_t blockLow[3], blockHigh[3];
+    if (threadIdx.x < 3)
     {
-        const float* r = store + 13 * i;
-        const int64_t x = static_cast<int64_t>(__builtin_floor(static_cast<double>(r[0]) * invCellSize));
-        const int64_t y = static_cast<int64_t>(__builtin_floor(static_cast<double>(r[1]) * invCellSize));
-        const int64_t z = static_cast<int64_t>(__builtin_floor(static_cast<double>(r[2]) * invCellSize));
-        const bool fits = x >= -kPackLimit && x < kPackLimit && y >= -kPackLimit && y < kPackLimit && z >= -kPackLimit &&
-                          z < kPackLimit;
-        keys[i] = fits ? packCell(x, y, z) : kEmptyKey;
-        order[i] = static_cast<uint32_t>(i);
-        if (fits)
+        blockLow[threadIdx.x] = INT32_MAX;
+        blockHigh[threadIdx.x] = INT32_MIN;
+    }
+    __syncthreads();
+    int32_t low[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, high[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n;
+         i += static_cast<uint64_t>(gridDim.x) * blockDim.x)
+    {
+        int64_t c[3];
+        if (recordCell(store + 13 * i, invCellSize, &c[0], &c[1], &c[2]))
         {
-            low[0] = high[0] = static_cast<int32_t>(x);
-            low[1] = high[1] = static_cast<int32_t>(y);
-            low[2] = high[2] = static_cast<int32_t>(z);
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+            {
+                low[k] = min(low[k], static_cast<int32_t>(c[k]));
+                high[k] = max(high[k], static_cast<int32_t>(c[k]));
+            }
         }
     }
-    if (cellBox == nullptr) return;
-    // the box of the cells that pack: one pair of atomics per wave and axis
 #pragma unroll
     for (int k = 0; k < 3; ++k)
     {
@@ -1335,37 +1352,49 @@ __global__ void storeKeysKernel(const float* store, uint64_t n, double invCellSi
             low[k] = min(low[k], __shfl_xor(low[k], step));
             high[k] = max(high[k], __shfl_xor(high[k], step));
         }
-    }
-    if ((threadIdx.x & 63) == 0 && low[0] <= high[0])
-    {
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
+        if ((threadIdx.x & 63) == 0 && low[k] <= high[k])
         {
-            // the box settles after a few waves: look before asking for the atomic, or every wave of
-            // the launch queues up at the same six words
-            if (low[k] < __hip_atomic_load(cellBox + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(cellBox + k, low[k]);
-            if (high[k] > __hip_atomic_load(cellBox + 3 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-            {
-                atomicMax(cellBox + 3 + k, high[k]);
-            }
+            atomicMin(&blockLow[k], low[k]);
+            atomicMax(&blockHigh[k], high[k]);
         }
     }
+    __syncthreads();
+    if (threadIdx.x < 3 && blockLow[threadIdx.x] <= blockHigh[threadIdx.x])
+    {
+        const int k = static_cast<int>(threadIdx.x);
+        if (blockLow[k] < __hip_atomic_load(cellBox + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(cellBox + k, blockLow[k]);
+        if (blockHigh[k] > __hip_atomic_load(cellBox + 3 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        {
+            atomicMax(cellBox + 3 + k, blockHigh[k]);
+        }
+    }
+}
+
+__global__ void storeKeysKernel(const float* store, uint64_t n, double invCellSize, KeyLayout layout, unsigned long long* keys,
+                                uint32_t* order)
+{
+    const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int64_t x, y, z;
+    const bool fits = recordCell(store + 13 * i, invCellSize, &x, &y, &z);
+    keys[i] = fits ? cellKey(layout, x, y, z) : kEmptyKey;
+    order[i] = static_cast<uint32_t>(i);
 }
 
 // Where a cell's records start in the sorted key list (GatherArgs::cellStart).
 struct CellBox
 {
-    int32_t low[3], dim[3];  // dim[0] == 1 with low[0] == INT32_MIN: rows, whatever their cells
+    KeyLayout layout;
+    int32_t dim[3];  // dim[0] == 1: a directory of rows, whatever their cells
 };
 
 RT_DEV uint32_t cellNumber(const CellBox& box, unsigned long long key)
 {
-    const int32_t x = box.low[0] == INT32_MIN
-                          ? 0
-                          : static_cast<int32_t>(static_cast<int64_t>(key & ((1ull << 21) - 1)) - kPackLimit) - box.low[0];
-    const int32_t y = static_cast<int32_t>(static_cast<int64_t>((key >> 21) & ((1ull << 21) - 1)) - kPackLimit) - box.low[1];
-    const int32_t z = static_cast<int32_t>(static_cast<int64_t>(key >> 42) - kPackLimit) - box.low[2];
-    return static_cast<uint32_t>((z * box.dim[1] + y) * box.dim[0] + x);
+    const KeyLayout& l = box.layout;
+    const uint32_t x = box.dim[0] == 1 ? 0u : static_cast<uint32_t>(key & ((1ull << l.bitsX) - 1));
+    const uint32_t y = static_cast<uint32_t>((key >> l.bitsX) & ((1ull << l.bitsY) - 1));
+    const uint32_t z = static_cast<uint32_t>(key >> (l.bitsX + l.bitsY));
+    return (z * static_cast<uint32_t>(box.dim[1]) + y) * static_cast<uint32_t>(box.dim[0]) + x;
 }
 
 // every cell's first record; cells without records keep the fill value (no record: UINT32_MAX)
@@ -1409,7 +1438,6 @@ __global__ void countIndexedKernel(const unsigned long long* keys, uint64_t n, u
     out[0] = lowerBound(keys, n, kEmptyKey);
 }
 
-RT_DEV int64_t clampCell(int64_t v) { return v < -kPackLimit ? -kPackLimit : (v > kPackLimit - 1 ? kPackLimit - 1 : v); }
 
 // The directory entries that bound the records of cells x0..x1 of the rows ya..yb of slab z: the
 // records lie in [cellStart[*from], cellStart[*to]) — exactly those records with a directory of cells
@@ -1486,12 +1514,11 @@ RT_DEV Color gatherRadiance(const GatherArgs& a, const GatherPoint& gp, uint32_t
     const int64_t cy = static_cast<int64_t>(__builtin_floor(position.y * a.invCellSize));
     const int64_t cz = static_cast<int64_t>(__builtin_floor(position.z * a.invCellSize));
     const int64_t reach = static_cast<int64_t>(__builtin_ceil(r * a.invCellSize));
-    // the cube of cells, cut to the range that records can occupy
-    const int64_t x0 = clampCell(cx - reach), x1 = clampCell(cx + reach);
-    const int64_t y0 = clampCell(cy - reach), y1 = clampCell(cy + reach);
-    const int64_t z0 = clampCell(cz - reach), z1 = clampCell(cz + reach);
-    if (cx + reach < -kPackLimit || cx - reach >= kPackLimit || cy + reach < -kPackLimit || cy - reach >= kPackLimit ||
-        cz + reach < -kPackLimit || cz - reach >= kPackLimit)
+    // the cube of cells, cut to the box of the cells that hold records (the keys are relative to it)
+    const int64_t x0 = max(cx - reach, static_cast<int64_t>(a.layout.low[0])), x1 = min(cx + reach, static_cast<int64_t>(a.layout.high[0]));
+    const int64_t y0 = max(cy - reach, static_cast<int64_t>(a.layout.low[1])), y1 = min(cy + reach, static_cast<int64_t>(a.layout.high[1]));
+    const int64_t z0 = max(cz - reach, static_cast<int64_t>(a.layout.low[2])), z1 = min(cz + reach, static_cast<int64_t>(a.layout.high[2]));
+    if (x0 > x1 || y0 > y1 || z0 > z1)
     {
         return black;
     }
@@ -1565,12 +1592,12 @@ RT_DEV Color gatherRadiance(const GatherArgs& a, const GatherPoint& gp, uint32_t
         // the rows' first and last keys are recomputed where they are needed rather than kept (registers)
         auto firstKey = [&](int k) {
             const int row = rowBase + k;
-            return row < rowCount ? packCell(x0, y0 + row % rowsPerSlab, z0 + row / rowsPerSlab) : kEmptyKey;
+            return row < rowCount ? cellKey(a.layout, x0, y0 + row % rowsPerSlab, z0 + row / rowsPerSlab) : kEmptyKey;
         };
         auto lastKey = [&](int k) {
             const int row = rowBase + k;
             const int64_t y = y0 + row % rowsPerSlab, z = z0 + row / rowsPerSlab;
-            return bySlab ? packCell(x1, y1, z) : packCell(x1, y, z);
+            return bySlab ? cellKey(a.layout, x1, y1, z) : cellKey(a.layout, x1, y, z);
         };
         // Records [lo, hi) of every row.  With a directory of cells these are two of its entries; with a
         // directory of rows (or none) the entries (or the whole list) bound two binary searches, for the
@@ -1704,7 +1731,7 @@ RT_DEV Color gatherRadiance(const GatherArgs& a, const GatherPoint& gp, uint32_t
                     }
                     if (bySlab)
                     {
-                        const int64_t kx = static_cast<int64_t>(key[u] & ((1ull << 21) - 1)) - kPackLimit;
+                        const int64_t kx = keyCellX(a.layout, key[u]);
                         if (kx < x0 || kx > x1)
                         {
                             continue;
@@ -1844,11 +1871,11 @@ RT_DEV Color gatherRadianceGroup(const GatherArgs& a, const GatherPoint& gp, int
     const int64_t cy = static_cast<int64_t>(__builtin_floor(position.y * a.invCellSize));
     const int64_t cz = static_cast<int64_t>(__builtin_floor(position.z * a.invCellSize));
     const int64_t reach = static_cast<int64_t>(__builtin_ceil(r * a.invCellSize));
-    const int64_t x0 = clampCell(cx - reach), x1 = clampCell(cx + reach);
-    const int64_t y0 = clampCell(cy - reach), y1 = clampCell(cy + reach);
-    const int64_t z0 = clampCell(cz - reach), z1 = clampCell(cz + reach);
-    if (cx + reach < -kPackLimit || cx - reach >= kPackLimit || cy + reach < -kPackLimit || cy - reach >= kPackLimit ||
-        cz + reach < -kPackLimit || cz - reach >= kPackLimit)
+    // the cube of cells, cut to the box of the cells that hold records (the keys are relative to it)
+    const int64_t x0 = max(cx - reach, static_cast<int64_t>(a.layout.low[0])), x1 = min(cx + reach, static_cast<int64_t>(a.layout.high[0]));
+    const int64_t y0 = max(cy - reach, static_cast<int64_t>(a.layout.low[1])), y1 = min(cy + reach, static_cast<int64_t>(a.layout.high[1]));
+    const int64_t z0 = max(cz - reach, static_cast<int64_t>(a.layout.low[2])), z1 = min(cz + reach, static_cast<int64_t>(a.layout.high[2]));
+    if (x0 > x1 || y0 > y1 || z0 > z1)
     {
         return black;
     }
@@ -1877,8 +1904,8 @@ RT_DEV Color gatherRadianceGroup(const GatherArgs& a, const GatherPoint& gp, int
                 myEnd = listed ? a.cellStart[to] : static_cast<uint32_t>(a.indexed);
                 if (a.directoryKind != kDirectoryCells)
                 {
-                    const unsigned long long first = packCell(x0, y, z);
-                    const unsigned long long last = bySlab ? packCell(x1, y1, z) : packCell(x1, y, z);
+                    const unsigned long long first = cellKey(a.layout, x0, y, z);
+                    const unsigned long long last = bySlab ? cellKey(a.layout, x1, y1, z) : cellKey(a.layout, x1, y, z);
                     myStart += static_cast<uint32_t>(lowerBound(a.keys + myStart, myEnd - myStart, first));
                     myEnd = myStart + static_cast<uint32_t>(lowerBound(a.keys + myStart, myEnd - myStart, last + 1));
                 }
@@ -1909,7 +1936,7 @@ RT_DEV Color gatherRadianceGroup(const GatherArgs& a, const GatherPoint& gp, int
                 bool passes = !beyond;
                 if (passes && bySlab)
                 {
-                    const int64_t kx = static_cast<int64_t>(key & ((1ull << 21) - 1)) - kPackLimit;
+                    const int64_t kx = keyCellX(a.layout, key);
                     passes = kx >= x0 && kx <= x1;
                 }
                 Color contribution = black;
@@ -2466,8 +2493,10 @@ void launchGatherWrite(const SceneView& scene, int32_t camera, int32_t stride, i
 }
 
 hipError_t buildCellDirectory(void* scratch, size_t* scratchBytes, const unsigned long long* sortedKeys, uint64_t indexed,
-                              const int32_t cellMin[3], const int32_t cellDim[3], uint32_t* cellStart, hipStream_t stream)
+                              const KeyLayout& layout, const int32_t cellMin[3], const int32_t cellDim[3], uint32_t* cellStart,
+                              hipStream_t stream)
 {
+    (void)cellMin;  // the keys are relative to the box already
     const size_t cells = static_cast<size_t>(cellDim[0]) * static_cast<size_t>(cellDim[1]) * static_cast<size_t>(cellDim[2]);
     // an empty cell starts where the next cell with records does: a running minimum from the end
     rocprim::reverse_iterator<uint32_t*> fromEnd(cellStart + cells + 1);
@@ -2479,9 +2508,9 @@ hipError_t buildCellDirectory(void* scratch, size_t* scratchBytes, const unsigne
     const hipError_t status = hipMemsetAsync(cellStart, 0xFF, (cells + 1) * sizeof(uint32_t), stream);
     if (status != hipSuccess) return status;
     CellBox box;
+    box.layout = layout;
     for (int k = 0; k < 3; ++k)
     {
-        box.low[k] = cellMin[k];
         box.dim[k] = cellDim[k];
     }
     hipLaunchKernelGGL(cellFirstsKernel, dim3(gridFor(static_cast<int64_t>(indexed))), dim3(256), 0, stream, sortedKeys, indexed,
@@ -2489,21 +2518,50 @@ hipError_t buildCellDirectory(void* scratch, size_t* scratchBytes, const unsigne
     return rocprim::inclusive_scan(scratch, *scratchBytes, fromEnd, fromEnd, cells + 1, rocprim::minimum<uint32_t>(), stream);
 }
 
-void launchStoreKeys(const float* store, uint64_t n, double invCellSize, unsigned long long* keys, uint32_t* order,
-                     int32_t* cellBox, hipStream_t stream)
+void launchStoreBox(const float* store, uint64_t n, double invCellSize, int32_t* cellBox, hipStream_t stream)
+{
+    if (n == 0) return;
+    const int64_t blocks = std::min<int64_t>(2048, static_cast<int64_t>((n + 255) / 256));
+    hipLaunchKernelGGL(storeBoxKernel, dim3(static_cast<uint32_t>(blocks)), dim3(256), 0, stream, store, n, invCellSize, cellBox);
+}
+
+KeyLayout keyLayoutFor(const int32_t box[6])
+{
+    KeyLayout l{};
+    int bits[3] = {0, 0, 0};
+    for (int k = 0; k < 3; ++k)
+    {
+        l.low[k] = box[k];
+        l.high[k] = box[3 + k];
+        if (box[k] > box[3 + k])
+        {
+            l.low[k] = l.high[k] = 0;  // no record packs: nothing is keyed
+        }
+        // the greatest coordinate of the part, and for z one more (its all-ones value stays unused)
+        const uint64_t most = static_cast<uint64_t>(static_cast<int64_t>(l.high[k]) - l.low[k]) + (k == 2 ? 1 : 0);
+        while ((1ull << bits[k]) <= most) ++bits[k];
+    }
+    l.bitsX = bits[0];
+    l.bitsY = bits[1];
+    l.bits = bits[0] + bits[1] + bits[2];
+    return l;
+}
+
+void launchStoreKeys(const float* store, uint64_t n, double invCellSize, const KeyLayout& layout, unsigned long long* keys,
+                     uint32_t* order, hipStream_t stream)
 {
     if (n == 0) return;
     hipLaunchKernelGGL(storeKeysKernel, dim3(gridFor(static_cast<int64_t>(n))), dim3(256), 0, stream, store, n,
-                       invCellSize, keys, order, cellBox);
+                       invCellSize, layout, keys, order);
 }
 
 hipError_t sortStoreKeys(void* scratch, size_t* scratchBytes, const unsigned long long* keysIn,
-                         unsigned long long* keysOut, const uint32_t* orderIn, uint32_t* orderOut, uint64_t n,
+                         unsigned long long* keysOut, const uint32_t* orderIn, uint32_t* orderOut, uint64_t n, int bits,
                          hipStream_t stream)
 {
     // radix sort is stable: records of one cell keep their store order
     return hipcub::DeviceRadixSort::SortPairs(scratch, *scratchBytes, keysIn, keysOut, orderIn, orderOut,
-                                              static_cast<int>(n), 0, 64, stream);
+                                              static_cast<int>(n), 0, std::max(1, std::min(64, bits)), stream);
 }
 
 namespace
