@@ -1768,14 +1768,17 @@ rtd::TraceArgs passArguments(const rt_tracer* tracer, const rt_trace_params* par
     return args;
 }
 
-// Run lengths of one launch over `work` items: every resident wave should see several runs, so
-// small launches use short runs, and the last sixteenth of a launch goes out in pieces a quarter
-// as long so that the waves end together.  Returns the number of blocks to launch.
-int scheduleLaunch(rtd::TraceArgs& launch, uint64_t work, int residentBlocks, bool ordered)
+// Run lengths of one launch over `work` items: every resident wave should see `runsPerWaveWanted` runs (so
+// small launches use short runs; at most 4096 positions a run, 256 for an unordered list), and the last
+// sixteenth of a launch goes out in pieces a quarter as long so that the waves end together.  Returns the
+// number of blocks to launch.
+int scheduleLaunch(rtd::TraceArgs& launch, uint64_t work, int residentBlocks, bool ordered, int runsPerWaveWanted)
 {
     const uint64_t wavesPerBlock = static_cast<uint64_t>(rtd::traceBlockThreads()) / 64;
     const uint64_t waves = static_cast<uint64_t>(residentBlocks) * wavesPerBlock;
-    uint64_t chunk = work / (waves * 4);
+    uint64_t runsPerWave = static_cast<uint64_t>(std::max(1, runsPerWaveWanted));
+    if (const char* v = std::getenv("RT_AMD_RUNS_PER_WAVE")) runsPerWave = std::max<uint64_t>(1, std::strtoull(v, nullptr, 10));
+    uint64_t chunk = work / (waves * runsPerWave);
     // parked photons are in no particular order: short runs, for balance
     chunk = std::min<uint64_t>(ordered ? 4096 : 256, std::max<uint64_t>(64, chunk)) & ~63ull;
     launch.chunk = static_cast<uint32_t>(chunk);
@@ -1966,7 +1969,17 @@ int32_t rt_trace(rt_tracer* tracer, const rt_trace_params* params)
             {
                 launch.queueInOrder = tracer->queueOrder.ptr;
             }
-            const int blocks = scheduleLaunch(launch, work, residentBlocks, level == 0 || sortedLevel);
+            // Runs per wave.  Where photons stay in their lanes for several bounces (no bounce levels, or
+            // the launch after the last level), lanes refill one by one and a wave that changes runs often is
+            // a wave whose lanes stand in different corners of the scene: four long runs per wave.  A launch
+            // whose photons all make one bounce and leave can take shorter runs, so that the waves end
+            // together: sixteen per wave for parked photons (their bounces are the expensive, divergent
+            // ones: MirrorKnot4k 24.8 -> 20.7 ms), eight for the emission (short runs cost a cheap scene
+            // more than balance gains it: CornellBox prefers four, a 25 M share of Bombardment sixteen).
+            // (RT_AMD_RUNS_PER_WAVE overrides.)
+            const bool oneTrip = level < levels || (levels > 0 && levels >= tracer->settings.bounce_threshold);
+            const int runsPerWave = !oneTrip ? 4 : (level == 0 ? 8 : 16);
+            const int blocks = scheduleLaunch(launch, work, residentBlocks, level == 0 || sortedLevel, runsPerWave);
             if (level > 0) launch.claimStride = 1;
             const auto levelStart = std::chrono::steady_clock::now();
             check(rtd::launchTrace(launch, blocks, tracer->stream), "trace launch");
@@ -2058,7 +2071,7 @@ int32_t rt_trace_static(rt_tracer* tracer, const rt_trace_params* params)
         check(hipGetLastError(), "emission sort");
         args.emissionOrder = idsOut;
         const int residentBlocks = tracer->computeUnits * rtd::traceBlocksPerCu(args);
-        const int blocks = scheduleLaunch(args, args.totalWork, residentBlocks, true);
+        const int blocks = scheduleLaunch(args, args.totalWork, residentBlocks, true, 4);
         check(rtd::launchTrace(args, blocks, tracer->stream), "trace launch");
     });
 }
