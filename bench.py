@@ -178,6 +178,12 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE={os.environ['WORLD_SIZE']}: "
                          "launch one rank per GPU and pass their number as --gpus")
 
+    # Rank 0's JSON line is the only thing this process writes to its standard output: libraries that
+    # print there (RCCL's version banner when a communicator is made) are sent to standard error.
+    result_out = os.fdopen(os.dup(1), "w")
+    sys.stdout.flush()
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
@@ -366,7 +372,7 @@ def main():
             assert roofline[key] is None or 0.0 < roofline[key] <= 1.0, roofline
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(rt, args.scene, sink, setup, args.cpu_photons)
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=result_out, flush=True)
 
     if collective:
         dist.destroy_process_group()

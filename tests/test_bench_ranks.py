@@ -26,8 +26,8 @@ def run_bench(ranks, photons, launcher=True, extra=()):
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
     r = subprocess.run(cmd, cwd=REPO, capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
-    lines = [line for line in r.stdout.splitlines() if line.startswith("{")]
-    assert len(lines) == 1, "exactly one JSON line, from rank 0"
+    lines = [line for line in r.stdout.splitlines() if line.strip()]
+    assert len(lines) == 1, "standard output is exactly one JSON line, from rank 0: " + r.stdout[:400]
     return json.loads(lines[0])
 
 
