@@ -185,11 +185,20 @@ int32_t rt_trace_static(rt_tracer* tracer, const rt_trace_params* params);
 uint64_t rt_trace_static_max_photons(void);
 
 /* Device time of the last rt_trace, from HIP events recorded on the tracer's stream around
- * its two stages: the emission-order sort of the photon ids (keys + radix sort; 0 when the
- * pass has 2^31 ids or more and is traced unsorted) and the trace kernel.  The reference reports one wall time for the whole pass
+ * its two stages: the emission-order sort of the photon ids (a bucket sort by emission cell for a
+ * pass of one light and 4 Mi ids or more, else keys + radix sort; 0 when the pass has 2^31 ids or
+ * more and is traced unsorted) and the trace kernel.  The reference reports one wall time for the whole pass
  * (RenderResult::photonPassSeconds, include/Renderer.h:51-103); the split is what a
  * per-kernel roofline needs.  Waits for the pass to finish. */
 int32_t rt_read_timings(rt_tracer* tracer, float* sort_ms, float* trace_ms);
+
+/* The emission order the last rt_trace worked out (or reused): photon ids of the pass, numbered light
+ * by light from 0, in the order the waves claim them.  The reference has no such list (its workers take
+ * photons in index order, src/Worker.cpp:429-505); it is exposed so that the schedule can be checked to
+ * be a permutation of the pass and ordered by emission cell.  *count receives the length of the list
+ * (0: the last pass was traced unsorted); at most `capacity` ids are copied to `ids` (host memory).
+ * Waits for the stream. */
+int32_t rt_read_emission_order(rt_tracer* tracer, uint32_t* ids, uint64_t capacity, uint64_t* count);
 
 int32_t rt_read_counters(rt_tracer* tracer, rt_counters* out);
 

@@ -6,6 +6,7 @@
 
 #include "rt_bvh.h"
 #include "rt_kernels.h"
+#include "rt_order.h"
 
 #include <algorithm>
 #include <array>
@@ -165,6 +166,7 @@ unsigned char* staticScratchOf(int device)
 constexpr int kQueueLevels = 12;
 constexpr uint64_t kQueueCapacity = 48ull << 20;  // photons parked per level at most (4.5 GB per queue)
 constexpr uint64_t kQueueMinimumWork = 4ull << 20;  // smaller passes are traced in one launch
+constexpr uint64_t kRefineOrderMinimum = 4ull << 20;  // smaller passes are radix-sorted over all the bits of their keys
 
 struct rt_tracer
 {
@@ -220,7 +222,9 @@ struct rt_tracer
     DeviceArray<rtd::DeviceCounters> counters;
     // emission-order list of a pass's photon ids
     DeviceArray<uint32_t> sortIds, sortOrder, sortKeysIn, sortKeysOut;
+    const uint32_t* orderList = nullptr;          // the finished emission order: sortOrder or (large passes) sortIds
     uint64_t orderedFirst = 0, orderedCount = 0;  // the range of photons per light sortOrder holds the order of (0: none)
+    uint64_t orderedLength = 0;                   // ids in the emission order of the last rt_trace (0: traced unsorted)
     DeviceArray<rtd::PhotonState> photonQueue[2];
     // keys of the parked photons' rays, their sorted copy, the slot numbers in key order, 0..n-1
     DeviceArray<uint32_t> queueKeys, queueKeysSorted, queueOrder, queueIota;
@@ -1360,7 +1364,7 @@ int32_t rt_create(const rt_scene* scene, int32_t device, rt_tracer** out)
         t->computeUnits = prop.multiProcessorCount;
         t->staticScratch = staticScratchOf(device);
         check(rtd::sortEmissionPairs(nullptr, &t->staticSortBytes, nullptr, nullptr, nullptr, nullptr, kStaticMaxIds,
-                                     static_cast<int>(std::max<int64_t>(1, t->lightCount)), nullptr),
+                                     static_cast<int>(std::max<int64_t>(1, t->lightCount)), 0, nullptr),
               "sort size query");
         resetState(t.get());
         check(hipStreamSynchronize(t->stream), "hipStreamSynchronize");
@@ -1837,6 +1841,7 @@ int32_t rt_trace(rt_tracer* tracer, const rt_trace_params* params)
 
         // a fresh range of photon ids for this launch
         check(hipMemsetAsync(tracer->scalars.ptr, 0, sizeof(unsigned long long), tracer->stream), "hipMemsetAsync");
+        tracer->orderedLength = 0;
         if (args.totalWork == 0)
         {
             return;
@@ -1851,7 +1856,16 @@ int32_t rt_trace(rt_tracer* tracer, const rt_trace_params* params)
         args.emissionOrder = nullptr;
         if (args.totalWork < (1ull << 31))
         {
+            tracer->orderedLength = args.totalWork;
             const uint64_t n = args.totalWork;
+            const int lights = static_cast<int>(tracer->lightCount);
+            // Large passes leave the keys' low bits out of the radix sort and settle them run by run in
+            // LDS (rt_order.h); RT_AMD_EMISSION_SORT=radix|refine overrides the choice.
+            bool refine = n >= kRefineOrderMinimum;
+            if (const char* v = std::getenv("RT_AMD_EMISSION_SORT"))
+            {
+                refine = std::strcmp(v, "radix") != 0;
+            }
             if (tracer->sortOrder.count < n)
             {
                 tracer->sortOrder.allocate(n);
@@ -1864,24 +1878,31 @@ int32_t rt_trace(rt_tracer* tracer, const rt_trace_params* params)
             // caller that traces the same range again (the frames of a sequence) may ask for the list the
             // last pass left (RT_TRACE_REUSE_ORDER).
             const bool reuse = (params->flags & RT_TRACE_REUSE_ORDER) != 0 && tracer->orderedCount == args.photonCount &&
-                               tracer->orderedFirst == args.firstPhoton;
+                               tracer->orderedFirst == args.firstPhoton && tracer->orderList != nullptr;
             if (!reuse)
             {
                 rtd::launchEmissionKeys(args, tracer->sortKeysIn.ptr, tracer->sortIds.ptr, tracer->stream);
-                const int lights = static_cast<int>(tracer->lightCount);
+                const int skipBits = refine ? rtd::kRefineBits : 0;
                 size_t bytes = 0;
                 check(rtd::sortEmissionPairs(nullptr, &bytes, tracer->sortKeysIn.ptr, tracer->sortKeysOut.ptr, tracer->sortIds.ptr,
-                                             tracer->sortOrder.ptr, n, lights, tracer->stream),
+                                             tracer->sortOrder.ptr, n, lights, skipBits, tracer->stream),
                       "sort size query");
                 if (tracer->sortScratch.count < bytes) tracer->sortScratch.allocate(bytes);
                 check(rtd::sortEmissionPairs(tracer->sortScratch.ptr, &bytes, tracer->sortKeysIn.ptr, tracer->sortKeysOut.ptr,
-                                             tracer->sortIds.ptr, tracer->sortOrder.ptr, n, lights, tracer->stream),
+                                             tracer->sortIds.ptr, tracer->sortOrder.ptr, n, lights, skipBits, tracer->stream),
                       "emission sort");
+                tracer->orderList = tracer->sortOrder.ptr;
+                if (refine)
+                {
+                    // the list of unsorted ids has been read: it takes the finished order
+                    rtd::launchRefineOrder(tracer->sortKeysOut.ptr, tracer->sortOrder.ptr, n, tracer->sortIds.ptr, tracer->stream);
+                    tracer->orderList = tracer->sortIds.ptr;
+                }
                 check(hipGetLastError(), "emission sort");
                 tracer->orderedCount = args.photonCount;
                 tracer->orderedFirst = args.firstPhoton;
             }
-            args.emissionOrder = tracer->sortOrder.ptr;
+            args.emissionOrder = tracer->orderList;
         }
         check(hipEventRecord(tracer->stageEvents[1], tracer->stream), "hipEventRecord");
         // the persistent grid fills the chip with the variant this pass runs
@@ -2047,6 +2068,7 @@ int32_t rt_trace_static(rt_tracer* tracer, const rt_trace_params* params)
         }
         tracer->recordPhotons = 0;  // the buffers of an earlier rt_trace stay allocated and are not read
         tracer->timed = false;
+        tracer->orderedLength = 0;  // this pass's order lives in the static array
         if (args.totalWork == 0)
         {
             return;
@@ -2066,13 +2088,28 @@ int32_t rt_trace_static(rt_tracer* tracer, const rt_trace_params* params)
         rtd::launchEmissionKeys(args, keysIn, idsIn, tracer->stream);
         size_t bytes = kStaticSortBytes;
         check(rtd::sortEmissionPairs(sortSpace, &bytes, keysIn, keysOut, idsIn, idsOut, args.totalWork,
-                                     static_cast<int>(tracer->lightCount), tracer->stream),
+                                     static_cast<int>(tracer->lightCount), 0, tracer->stream),
               "emission sort");
         check(hipGetLastError(), "emission sort");
         args.emissionOrder = idsOut;
         const int residentBlocks = tracer->computeUnits * rtd::traceBlocksPerCu(args);
         const int blocks = scheduleLaunch(args, args.totalWork, residentBlocks, true, 4);
         check(rtd::launchTrace(args, blocks, tracer->stream), "trace launch");
+    });
+}
+
+int32_t rt_read_emission_order(rt_tracer* tracer, uint32_t* ids, uint64_t capacity, uint64_t* count)
+{
+    return guarded([&]() {
+        require(tracer != nullptr && count != nullptr && (ids != nullptr || capacity == 0), "null argument");
+        activate(tracer);
+        check(hipStreamSynchronize(tracer->stream), "hipStreamSynchronize");
+        *count = tracer->orderedLength;
+        const uint64_t n = std::min<uint64_t>(capacity, tracer->orderedLength);
+        if (n > 0)
+        {
+            check(hipMemcpy(ids, tracer->orderList, n * sizeof(uint32_t), hipMemcpyDeviceToHost), "hipMemcpy D2H");
+        }
     });
 }
 

@@ -144,8 +144,10 @@ size_t traceCacheBudget(int stackDepth);   // LDS bytes a trace block has for th
 // *scratchBytes receives the work space the call needs; the library's status is returned.
 void launchEmissionKeys(const TraceArgs& args, uint32_t* keys, uint32_t* ids, hipStream_t stream);
 
+// (skipBits: the sort leaves out that many of the keys' lowest bits)
 hipError_t sortEmissionPairs(void* scratch, size_t* scratchBytes, const uint32_t* keysIn, uint32_t* keysOut,
-                             const uint32_t* idsIn, uint32_t* idsOut, uint64_t n, int lightCount, hipStream_t stream);
+                             const uint32_t* idsIn, uint32_t* idsOut, uint64_t n, int lightCount, int skipBits,
+                             hipStream_t stream);
 void launchCastRays(const SceneView& scene, int64_t n, const double* rays, double selfHit, double* outF64,
                     int32_t* outI32, hipStream_t stream);
 void launchEmit(const SceneView& scene, int32_t light, int64_t n, const double* draws5, uint64_t totalPhotons,

@@ -12,6 +12,7 @@
 // registers and never stored.
 
 #include "rt_kernels.h"
+#include "rt_order.h"
 
 #include <algorithm>
 #include <cstdio>
@@ -569,89 +570,22 @@ RT_DEV void splatToCamera(const TraceArgs& a, bool splats, const Vec& incoming, 
 // the same nodes and finish their casts together.  A photon's path depends only on its id
 // (the counter-based draws), so the order changes nothing but the schedule.
 
-// A pass numbers its photons light by light: id = light * photonCount + (index - firstPhoton).
-// Most scenes have one light and most passes fit 32 bits; the 64-bit division is the last resort.
-RT_DEV void splitPhotonId(const TraceArgs& a, unsigned long long id, int* lightId, unsigned long long* photonIndex)
-{
-    if (id < a.photonCount)
-    {
-        *lightId = 0;
-        *photonIndex = a.firstPhoton + id;
-    }
-    else if (((id | a.photonCount) >> 32) == 0)
-    {
-        const uint32_t light = static_cast<uint32_t>(id) / static_cast<uint32_t>(a.photonCount);
-        *lightId = static_cast<int>(light);
-        *photonIndex = a.firstPhoton + (static_cast<uint32_t>(id) - light * static_cast<uint32_t>(a.photonCount));
-    }
-    else
-    {
-        *lightId = static_cast<int>(id / a.photonCount);
-        *photonIndex = a.firstPhoton + id % a.photonCount;
-    }
-}
-
 RT_DEV unsigned long long photonAt(const TraceArgs& a, unsigned long long position)
 {
     return a.emissionOrder ? static_cast<unsigned long long>(a.emissionOrder[position]) : position;
 }
 
 // Whole-pass emission order: every id gets a key that puts photons with nearly the same initial ray
-// next to each other, above it the light (so that lights do not interleave); a radix sort of
-// (key, id) then orders the whole pass.  A light that emits from a point is keyed by the Morton
-// number of its cell in a 4096 x 4096 grid over the two draws that steer the direction.  An area
-// light also draws the ray's origin on its face: rays of one direction that start a face apart share
-// nothing, so its key interleaves four draws, 64 cells each: origin (2) and direction (2).
-constexpr int kGlobalAxisBits = 12;
-
-RT_DEV uint32_t spreadBits12(uint32_t v)
-{
-    v = (v | (v << 8)) & 0x00FF00FFu;
-    v = (v | (v << 4)) & 0x0F0F0F0Fu;
-    v = (v | (v << 2)) & 0x33333333u;
-    v = (v | (v << 1)) & 0x55555555u;
-    return v;
-}
-
+// next to each other (emissionCell), above it the light (so that lights do not interleave); a radix
+// sort of (key, id) then orders the whole pass.
 __global__ void emissionKeysKernel(const TraceArgs a, uint32_t* keys, uint32_t* ids)
 {
     const unsigned long long id = static_cast<unsigned long long>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (id >= a.totalWork) return;
-    Rng rng;
-    rng.tape = nullptr;
-    rng.next = 0;
-    rng.seed = a.scene.seed;
     int lightId;
     unsigned long long photonIndex;
     splitPhotonId(a, id, &lightId, &photonIndex);
-    rng.begin(static_cast<uint32_t>(lightId), photonIndex, RT_STAGE_EMIT);
-    const double u0 = rng.value(), u1 = rng.value();
-    uint32_t cell;
-    if (a.scene.lights[lightId].type == RT_LIGHT_AREA)
-    {
-        // draws 1 and 2 place the origin on the face, 3 and 4 steer the direction
-        const double u2 = rng.value(), u3 = rng.value();
-        const double u[4] = {u0, u1, u2, u3};
-        cell = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-        {
-            const uint32_t c = static_cast<uint32_t>(u[k] * 64.0) & 63u;
-#pragma unroll
-            for (int bit = 0; bit < 6; ++bit)
-            {
-                cell |= ((c >> bit) & 1u) << (4 * bit + (3 - k));
-            }
-        }
-    }
-    else
-    {
-        const uint32_t axis = 1u << kGlobalAxisBits;
-        const uint32_t cx = static_cast<uint32_t>(u0 * axis) & (axis - 1);
-        const uint32_t cy = static_cast<uint32_t>(u1 * axis) & (axis - 1);
-        cell = spreadBits12(cx) | (spreadBits12(cy) << 1);
-    }
-    keys[id] = (static_cast<uint32_t>(lightId & 0xFF) << (2 * kGlobalAxisBits)) | cell;
+    keys[id] = (static_cast<uint32_t>(lightId & 0xFF) << (2 * kGlobalAxisBits)) | emissionCell(a, lightId, photonIndex);
     ids[id] = static_cast<uint32_t>(id);
 }
 
@@ -2380,12 +2314,13 @@ void launchEmissionKeys(const TraceArgs& args, uint32_t* keys, uint32_t* ids, hi
 }
 
 hipError_t sortEmissionPairs(void* scratch, size_t* scratchBytes, const uint32_t* keysIn, uint32_t* keysOut,
-                             const uint32_t* idsIn, uint32_t* idsOut, uint64_t n, int lightCount, hipStream_t stream)
+                             const uint32_t* idsIn, uint32_t* idsOut, uint64_t n, int lightCount, int skipBits,
+                             hipStream_t stream)
 {
     int lightBits = 0;
     while ((1 << lightBits) < lightCount && lightBits < 8) ++lightBits;
-    return hipcub::DeviceRadixSort::SortPairs(scratch, *scratchBytes, keysIn, keysOut, idsIn, idsOut, static_cast<int>(n), 0,
-                                              2 * kGlobalAxisBits + lightBits, stream);
+    return hipcub::DeviceRadixSort::SortPairs(scratch, *scratchBytes, keysIn, keysOut, idsIn, idsOut, static_cast<int>(n),
+                                              skipBits, 2 * kGlobalAxisBits + lightBits, stream);
 }
 
 namespace

@@ -57,6 +57,7 @@ _SIGNATURES = {
     "rt_comm_init_all": (C.c_int32, [C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_void_p)]),
     "rt_comm_destroy": (C.c_int32, [C.c_void_p]),
     "rt_read_timings": (C.c_int32, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "rt_read_emission_order": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
     "rt_read_counters": (C.c_int32, [C.c_void_p, C.POINTER(RtCounters)]),
     "rt_read_camera_buffer": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p]),
     "rt_read_store": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
@@ -224,6 +225,16 @@ class Tracer:
         sort_ms, trace_ms = C.c_float(), C.c_float()
         _check(tracer_lib().rt_read_timings(self._handle, C.byref(sort_ms), C.byref(trace_ms)))
         return float(sort_ms.value), float(trace_ms.value)
+
+    def emission_order(self):
+        """Photon ids of the last pass (numbered light by light from 0) in the order they were traced;
+        empty when the pass was traced unsorted."""
+        n = C.c_uint64(0)
+        _check(tracer_lib().rt_read_emission_order(self._handle, None, 0, C.byref(n)))
+        out = np.empty(int(n.value), dtype=np.uint32)
+        if out.size:
+            _check(tracer_lib().rt_read_emission_order(self._handle, out.ctypes.data_as(C.c_void_p), out.size, C.byref(n)))
+        return out
 
     # -- read-back ----------------------------------------------------------
     def counters(self):

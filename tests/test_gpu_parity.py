@@ -260,12 +260,90 @@ def test_probe_sink_store_equals_oracle(rt, scene_opener, name):
     assert c["store_size"] == small and c["store_dropped"] == ref["kept"] - small and c["store_attempted"] == ref["kept"]
 
 
-@pytest.mark.parametrize("name,photons", [("bombardment", 1_300_000), ("mixed", 250_000)])
-def test_sorted_pass_equals_oracle(rt, scene_opener, name, photons):
+def _philox_first_block(seed, light, photon):
+    """Words 0 and 2 of Philox4x32-10 block 0 of the emission stage (include/rt_portable.h) for an array
+    of photon indices: the leading bits of the first two emission draws."""
+    m0, m1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
+    mask = np.uint64(0xFFFFFFFF)
+    shift = np.uint64(32)
+    c = [photon.astype(np.uint64) & mask, photon.astype(np.uint64) >> shift, np.zeros(photon.shape, np.uint64),
+         np.zeros(photon.shape, np.uint64)]
+    k0, k1 = np.uint64(seed), np.uint64(light)
+    for _ in range(10):
+        p0, p1 = m0 * c[0], m1 * c[2]
+        c = [(p1 >> shift) ^ c[1] ^ k0, p1 & mask, (p0 >> shift) ^ c[3] ^ k1, p0 & mask]
+        k0, k1 = (k0 + np.uint64(0x9E3779B9)) & mask, (k1 + np.uint64(0xBB67AE85)) & mask
+    return c[0], c[2]
+
+
+def _spread12(v):
+    v = v.astype(np.uint32)
+    v = (v | (v << np.uint32(8))) & np.uint32(0x00FF00FF)
+    v = (v | (v << np.uint32(4))) & np.uint32(0x0F0F0F0F)
+    v = (v | (v << np.uint32(2))) & np.uint32(0x33333333)
+    v = (v | (v << np.uint32(1))) & np.uint32(0x55555555)
+    return v
+
+
+@pytest.mark.parametrize("name,sort,photons,first", [("bombardment", "radix", 1_300_000, 0),
+                                                     ("bombardment", "refine", 1_300_000, 12345),
+                                                     ("bombardment", "refine", 3_001, 0),
+                                                     ("bombardment", "default", 4_500_000, 0),
+                                                     ("cbgmd", "refine", 700_000, 3),
+                                                     ("mixed", "refine", 200_000, 3)])
+def test_emission_order_is_a_sorted_permutation(rt, scene_opener, name, sort, photons, first, monkeypatch):
+    """The schedule of a pass: every id of the pass exactly once, ascending by emission cell (the Morton
+    number of the cell of the first two emission draws in a 4096 x 4096 grid).  Large passes radix-sort
+    all but the key's low eight bits and settle those inside every run of 4096 positions: there the runs
+    follow each other in the order of the cell without its low bits, and inside a run the cell ascends
+    (the whole cell where the run spans few values of the leading bits, without some of its last bits
+    where it spans many).  Checked for
+    the radix sort over all bits, for the two-step order forced onto small passes (one of a range that
+    does not start at photon 0, one shorter than a run) and for the order a large pass picks by itself;
+    an area light's key interleaves four draws and several lights put the light above the cell: those
+    are only checked to be permutations here."""
+    if sort != "default":
+        monkeypatch.setenv("RT_AMD_EMISSION_SORT", sort)
+    entry = dict(SCENES[name], photons_per_light=photons + first)
+    scene, tracer, _ = _open(rt, scene_opener, entry)
+    tracer.reset()
+    tracer.trace(sink_mode=0, first_photon=first, photon_count=photons)
+    order = tracer.emission_order()
+    total = photons * scene.desc.light_count
+    assert order.size == total
+    assert np.array_equal(np.sort(order), np.arange(total, dtype=np.uint32)), "a permutation of the pass"
+    assert tracer.counters()["photons"] == total
+    if name != "bombardment":
+        return
+    seed = int(scene.settings.seed) if scene.settings.seeded else 0
+    w0, w2 = _philox_first_block(seed, 0, order.astype(np.uint64) + np.uint64(first))
+    cell = (_spread12(w0 >> np.uint64(20)) | (_spread12(w2 >> np.uint64(20)) << np.uint32(1))).astype(np.int64)
+    if sort == "radix":
+        assert np.all(np.diff(cell) >= 0), "ascending by emission cell"
+        return
+    last = -1
+    for begin in range(0, total, 4096):
+        run = cell[begin:begin + 4096]
+        assert (run >> 8).min() >= last, f"run at {begin}: the runs ascend by the cell's leading bits"
+        last = (run >> 8).max()
+        # a run that spans many values of the leading bits drops low bits until 2048 bins hold it
+        lowest, drop = (run[0] >> 8) << 8, 0
+        while (((run[-1] | 255) - lowest) >> drop) >= 2048:
+            drop += 1
+        assert np.all(np.diff((run - lowest) >> drop) >= 0), f"run at {begin}: ascending by the cell"
+
+
+@pytest.mark.parametrize("name,photons,sort", [("bombardment", 1_300_000, "default"), ("mixed", 250_000, "default"),
+                                               ("bombardment", 1_300_000, "refine"), ("mixed", 250_000, "refine"),
+                                               ("cbgmd", 1_100_000, "refine")])
+def test_sorted_pass_equals_oracle(rt, scene_opener, name, photons, sort, monkeypatch):
     """Passes are traced in emission order (radix sort of the ids by emission cell, the light above
-    it: the multi-light case interleaves lights in id order but not in the sorted order).
+    it: the multi-light case interleaves lights in id order but not in the sorted order; large passes
+    settle the key's low bits run by run after the sort, forced here onto small ones).
     The schedule must not change any result: same counters, same store multiset, same paths
     for the recorded photons (record slots follow photon ids, not the schedule)."""
+    if sort != "default":
+        monkeypatch.setenv("RT_AMD_EMISSION_SORT", sort)
     entry = dict(SCENES[name], photons_per_light=photons)
     scene, tracer, orc = _open(rt, scene_opener, entry)
     assert photons * scene.desc.light_count >= 1 << 20
