@@ -223,6 +223,7 @@ struct rt_tracer
     // emission-order list of a pass's photon ids
     DeviceArray<uint32_t> sortIds, sortOrder, sortKeysIn, sortKeysOut;
     const uint32_t* orderList = nullptr;          // the finished emission order: sortOrder or (large passes) sortIds
+    DeviceArray<uint32_t> orderCounts, orderOffsets;  // large passes: ids per digit and tile, and where each such run starts
     uint64_t orderedFirst = 0, orderedCount = 0;  // the range of photons per light sortOrder holds the order of (0: none)
     uint64_t orderedLength = 0;                   // ids in the emission order of the last rt_trace (0: traced unsorted)
     DeviceArray<rtd::PhotonState> photonQueue[2];
@@ -1859,8 +1860,8 @@ int32_t rt_trace(rt_tracer* tracer, const rt_trace_params* params)
             tracer->orderedLength = args.totalWork;
             const uint64_t n = args.totalWork;
             const int lights = static_cast<int>(tracer->lightCount);
-            // Large passes leave the keys' low bits out of the radix sort and settle them run by run in
-            // LDS (rt_order.h); RT_AMD_EMISSION_SORT=radix|refine overrides the choice.
+            // Large passes are ordered in three steps of which only one is a pass of the radix sort
+            // (rt_order.h); RT_AMD_EMISSION_SORT=radix|refine overrides the choice.
             bool refine = n >= kRefineOrderMinimum;
             if (const char* v = std::getenv("RT_AMD_EMISSION_SORT"))
             {
@@ -1879,25 +1880,51 @@ int32_t rt_trace(rt_tracer* tracer, const rt_trace_params* params)
             // last pass left (RT_TRACE_REUSE_ORDER).
             const bool reuse = (params->flags & RT_TRACE_REUSE_ORDER) != 0 && tracer->orderedCount == args.photonCount &&
                                tracer->orderedFirst == args.firstPhoton && tracer->orderList != nullptr;
-            if (!reuse)
+            if (!reuse && refine)
             {
-                rtd::launchEmissionKeys(args, tracer->sortKeysIn.ptr, tracer->sortIds.ptr, tracer->stream);
-                const int skipBits = refine ? rtd::kRefineBits : 0;
+                // bits 8-15 of the keys while the keys are made, the bits above by a radix pass, the low eight
+                // run by run in LDS (rt_order.h)
+                const uint64_t entries = rtd::digitMatrixEntries(n);
+                if (tracer->orderCounts.count < entries)
+                {
+                    tracer->orderCounts.allocate(entries);
+                    tracer->orderOffsets.allocate(entries);
+                }
                 size_t bytes = 0;
-                check(rtd::sortEmissionPairs(nullptr, &bytes, tracer->sortKeysIn.ptr, tracer->sortKeysOut.ptr, tracer->sortIds.ptr,
+                check(rtd::digitOrder(args, nullptr, &bytes, tracer->sortKeysIn.ptr, tracer->orderCounts.ptr, tracer->orderOffsets.ptr,
+                                      tracer->sortKeysOut.ptr, tracer->sortIds.ptr, tracer->stream),
+                      "scan size query");
+                if (tracer->sortScratch.count < bytes) tracer->sortScratch.allocate(bytes);
+                check(rtd::digitOrder(args, tracer->sortScratch.ptr, &bytes, tracer->sortKeysIn.ptr, tracer->orderCounts.ptr,
+                                      tracer->orderOffsets.ptr, tracer->sortKeysOut.ptr, tracer->sortIds.ptr, tracer->stream),
+                      "emission order, first digit");
+                // (the list of keys by id has been read: it takes the sorted keys)
+                const int skipBits = rtd::kRefineBits + rtd::kDigitBits;
+                check(rtd::sortEmissionPairs(nullptr, &bytes, tracer->sortKeysOut.ptr, tracer->sortKeysIn.ptr, tracer->sortIds.ptr,
                                              tracer->sortOrder.ptr, n, lights, skipBits, tracer->stream),
                       "sort size query");
                 if (tracer->sortScratch.count < bytes) tracer->sortScratch.allocate(bytes);
-                check(rtd::sortEmissionPairs(tracer->sortScratch.ptr, &bytes, tracer->sortKeysIn.ptr, tracer->sortKeysOut.ptr,
+                check(rtd::sortEmissionPairs(tracer->sortScratch.ptr, &bytes, tracer->sortKeysOut.ptr, tracer->sortKeysIn.ptr,
                                              tracer->sortIds.ptr, tracer->sortOrder.ptr, n, lights, skipBits, tracer->stream),
                       "emission sort");
+                rtd::launchRefineOrder(tracer->sortKeysIn.ptr, tracer->sortOrder.ptr, n, tracer->sortIds.ptr, tracer->stream);
+                tracer->orderList = tracer->sortIds.ptr;
+                check(hipGetLastError(), "emission sort");
+                tracer->orderedCount = args.photonCount;
+                tracer->orderedFirst = args.firstPhoton;
+            }
+            else if (!reuse)
+            {
+                rtd::launchEmissionKeys(args, tracer->sortKeysIn.ptr, tracer->sortIds.ptr, tracer->stream);
+                size_t bytes = 0;
+                check(rtd::sortEmissionPairs(nullptr, &bytes, tracer->sortKeysIn.ptr, tracer->sortKeysOut.ptr, tracer->sortIds.ptr,
+                                             tracer->sortOrder.ptr, n, lights, 0, tracer->stream),
+                      "sort size query");
+                if (tracer->sortScratch.count < bytes) tracer->sortScratch.allocate(bytes);
+                check(rtd::sortEmissionPairs(tracer->sortScratch.ptr, &bytes, tracer->sortKeysIn.ptr, tracer->sortKeysOut.ptr,
+                                             tracer->sortIds.ptr, tracer->sortOrder.ptr, n, lights, 0, tracer->stream),
+                      "emission sort");
                 tracer->orderList = tracer->sortOrder.ptr;
-                if (refine)
-                {
-                    // the list of unsorted ids has been read: it takes the finished order
-                    rtd::launchRefineOrder(tracer->sortKeysOut.ptr, tracer->sortOrder.ptr, n, tracer->sortIds.ptr, tracer->stream);
-                    tracer->orderList = tracer->sortIds.ptr;
-                }
                 check(hipGetLastError(), "emission sort");
                 tracer->orderedCount = args.photonCount;
                 tracer->orderedFirst = args.firstPhoton;

@@ -74,15 +74,32 @@ RT_DEV uint32_t emissionCell(const TraceArgs& a, int lightId, unsigned long long
     return spreadBits12(first[0] >> drop) | (spreadBits12(first[2] >> drop) << 1);
 }
 
-// Large passes are ordered in two steps: the radix sort of the (key, id) pairs leaves out the keys' lowest
-// kRefineBits bits (one pass of the sort less: every pass reads and writes every pair), then every run of
-// kRefineRun consecutive positions of that list is put in the order of the whole key inside LDS — one
-// coalesced read of the pairs and one write of the ids.  The order is a schedule (any permutation of the
-// ids is a correct one): a wave works through a run of at most kRefineRun positions, and inside such a run
-// the ids are then exactly as finely ordered as after a sort over all the bits.
+// Large passes are ordered in three steps, each of them one trip of the pairs through memory (a radix
+// sort over all 24 bits of the cell is three passes that read and write every pair, after a pass that
+// reads every key to count its digits):
+//   1. the ids are put in the order of bits 8-15 of their keys while the keys are made: every block takes
+//      a tile of consecutive ids, works out their keys (kept) and counts them by that digit in LDS, the
+//      counts go to a [digit][tile] matrix, one exclusive sum over the matrix is where every (digit, tile)
+//      starts, and the tiles then place their (key, id) pairs, gathered by digit in LDS so that whole runs
+//      are written.  No order has to be kept among equal digits (it is the first digit sorted), which is
+//      what makes the ranks a matter of LDS atomics;
+//   2. a stable radix pass (the library's) over the bits above;
+//   3. every run of kRefineRun consecutive positions of that list is put in the order of the whole key
+//      inside LDS.  The order is a schedule (any permutation of the ids is a correct one): a wave works
+//      through a run of at most kRefineRun positions, and inside such a run the ids are then exactly as
+//      finely ordered as after a sort over all the bits.
 constexpr int kRefineBits = 8;
 constexpr uint32_t kRefineRun = 4096;
-// keys / ids: the pairs in ascending order of (key >> kRefineBits); order: n words (the result)
+constexpr int kDigitBits = 8;               // step 1 sorts bits [kRefineBits, kRefineBits + kDigitBits)
+constexpr uint32_t kDigitTile = 8192;       // ids per tile of step 1
+inline uint64_t digitTiles(uint64_t n) { return (n + kDigitTile - 1) / kDigitTile; }
+inline uint64_t digitMatrixEntries(uint64_t n) { return digitTiles(n) << kDigitBits; }
+// Step 1.  keys: n words (every id's key: the light above the emission cell), counts / offsets:
+// digitMatrixEntries(n) words each, keysOut / idsOut: the pairs by digit.  With a null `scratch` nothing
+// runs and *scratchBytes receives the exclusive sum's work space.
+hipError_t digitOrder(const TraceArgs& args, void* scratch, size_t* scratchBytes, uint32_t* keys, uint32_t* counts,
+                      uint32_t* offsets, uint32_t* keysOut, uint32_t* idsOut, hipStream_t stream);
+// Step 3.  keys / ids: the pairs in ascending order of (key >> kRefineBits); order: n words (the result)
 void launchRefineOrder(const uint32_t* keys, const uint32_t* ids, uint64_t n, uint32_t* order, hipStream_t stream);
 
 }  // namespace rtd

@@ -1,13 +1,122 @@
-// rt_order.hip — the last step of a large pass's emission order (see rt_order.h).
+// rt_order.hip — the first and the last step of a large pass's emission order (see rt_order.h).
 #include "rt_order.h"
 
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 
 namespace rtd
 {
 
 namespace
 {
+
+constexpr int kDigitThreads = 512;
+constexpr int kDigitItems = kDigitTile / kDigitThreads;  // ids a thread takes
+constexpr uint32_t kDigits = 1u << kDigitBits;
+constexpr int kOrderXcds = 8;  // blocks go to the chip's eight XCDs in turn
+static_assert(kDigits <= kDigitThreads, "a thread per digit in the tile's scan");
+static_assert(kDigitTile <= 65536, "a pair's place in its tile is kept in 16 bits");
+
+// Tile of a block: block b runs on XCD b % 8, and an XCD's blocks take neighbouring tiles, whose runs of
+// one digit are neighbours in memory: the two parts of a line that two tiles share meet in one L2.
+RT_DEV uint64_t digitTileOfBlock(uint64_t tilesPerXcd)
+{
+    return (blockIdx.x % kOrderXcds) * tilesPerXcd + blockIdx.x / kOrderXcds;
+}
+
+RT_DEV uint32_t digitOf(uint32_t key) { return (key >> kRefineBits) & (kDigits - 1); }
+
+__global__ __launch_bounds__(kDigitThreads) void digitCountKernel(const TraceArgs a, uint64_t tiles, uint64_t tilesPerXcd,
+                                                                  uint32_t* keys, uint32_t* counts)
+{
+    __shared__ uint32_t histogram[kDigits];
+    const uint64_t tile = digitTileOfBlock(tilesPerXcd);
+    if (tile >= tiles) return;
+    if (threadIdx.x < kDigits) histogram[threadIdx.x] = 0;
+    __syncthreads();
+    const unsigned long long begin = tile * kDigitTile;
+#pragma unroll 4
+    for (int k = 0; k < kDigitItems; ++k)
+    {
+        const unsigned long long id = begin + static_cast<unsigned long long>(k) * kDigitThreads + threadIdx.x;
+        if (id < a.totalWork)
+        {
+            int lightId;
+            unsigned long long photonIndex;
+            splitPhotonId(a, id, &lightId, &photonIndex);
+            const uint32_t key =
+                (static_cast<uint32_t>(lightId & 0xFF) << (2 * kGlobalAxisBits)) | emissionCell(a, lightId, photonIndex);
+            keys[id] = key;
+            atomicAdd(&histogram[digitOf(key)], 1u);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < kDigits) counts[threadIdx.x * tiles + tile] = histogram[threadIdx.x];
+}
+
+__global__ __launch_bounds__(kDigitThreads) void digitScatterKernel(uint64_t n, uint64_t tiles, uint64_t tilesPerXcd,
+                                                                    const uint32_t* keys, const uint32_t* counts,
+                                                                    const uint32_t* offsets, uint32_t* keysOut, uint32_t* idsOut)
+{
+    __shared__ uint32_t cursor[kDigits];     // next free place of every digit in the gathered tile
+    __shared__ uint32_t localStart[kDigits]; // where the digit's run starts in the gathered tile ...
+    __shared__ uint32_t globalStart[kDigits];// ... and in the list
+    __shared__ uint32_t waveTotals[kDigitThreads / 64];
+    __shared__ uint32_t gatheredKey[kDigitTile];
+    __shared__ uint16_t gatheredFrom[kDigitTile];  // the pair's place in the tile: its id is the tile's first + that
+    const uint64_t tile = digitTileOfBlock(tilesPerXcd);
+    if (tile >= tiles) return;
+    const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    // exclusive sum of the tile's digit counts (a thread per digit)
+    const uint32_t mine = t < kDigits ? counts[t * tiles + tile] : 0u;
+    uint32_t inclusive = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1)
+    {
+        const uint32_t up = __shfl_up(inclusive, d, 64);
+        if (static_cast<int>(lane) >= d) inclusive += up;
+    }
+    if (lane == 63) waveTotals[wave] = inclusive;
+    __syncthreads();
+    if (t < kDigits)
+    {
+        uint32_t before = 0;
+        for (uint32_t w = 0; w < wave; ++w) before += waveTotals[w];
+        const uint32_t exclusive = before + inclusive - mine;
+        cursor[t] = exclusive;
+        localStart[t] = exclusive;
+        globalStart[t] = offsets[t * tiles + tile];
+    }
+    __syncthreads();
+    const unsigned long long begin = tile * kDigitTile;
+    const uint32_t count = n - begin < kDigitTile ? static_cast<uint32_t>(n - begin) : kDigitTile;
+#pragma unroll 4
+    for (int k = 0; k < kDigitItems; ++k)
+    {
+        const uint32_t i = static_cast<uint32_t>(k) * kDigitThreads + t;
+        if (i < count)
+        {
+            const uint32_t key = keys[begin + i];
+            const uint32_t at = atomicAdd(&cursor[digitOf(key)], 1u);
+            gatheredKey[at] = key;
+            gatheredFrom[at] = static_cast<uint16_t>(i);
+        }
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int k = 0; k < kDigitItems; ++k)
+    {
+        const uint32_t i = static_cast<uint32_t>(k) * kDigitThreads + t;
+        if (i < count)
+        {
+            const uint32_t key = gatheredKey[i];
+            const uint32_t digit = digitOf(key);
+            const uint32_t at = globalStart[digit] + (i - localStart[digit]);
+            keysOut[at] = key;
+            idsOut[at] = static_cast<uint32_t>(begin) + gatheredFrom[i];
+        }
+    }
+}
 
 constexpr int kRefineThreads = 256;
 constexpr int kRefineItems = kRefineRun / kRefineThreads;  // pairs a thread holds
@@ -134,6 +243,25 @@ __global__ __launch_bounds__(kRefineThreads) void refineOrderKernel(const uint32
 }
 
 }  // namespace
+
+hipError_t digitOrder(const TraceArgs& args, void* scratch, size_t* scratchBytes, uint32_t* keys, uint32_t* counts,
+                      uint32_t* offsets, uint32_t* keysOut, uint32_t* idsOut, hipStream_t stream)
+{
+    const uint64_t n = args.totalWork, tiles = digitTiles(n), entries = digitMatrixEntries(n);
+    if (scratch == nullptr)
+    {
+        return hipcub::DeviceScan::ExclusiveSum(nullptr, *scratchBytes, counts, offsets, static_cast<int>(entries), stream);
+    }
+    if (n == 0) return hipSuccess;
+    const uint64_t tilesPerXcd = (tiles + kOrderXcds - 1) / kOrderXcds;
+    const dim3 grid(static_cast<unsigned int>(tilesPerXcd * kOrderXcds)), block(kDigitThreads);
+    hipLaunchKernelGGL(digitCountKernel, grid, block, 0, stream, args, tiles, tilesPerXcd, keys, counts);
+    const hipError_t scanned =
+        hipcub::DeviceScan::ExclusiveSum(scratch, *scratchBytes, counts, offsets, static_cast<int>(entries), stream);
+    if (scanned != hipSuccess) return scanned;
+    hipLaunchKernelGGL(digitScatterKernel, grid, block, 0, stream, n, tiles, tilesPerXcd, keys, counts, offsets, keysOut, idsOut);
+    return hipGetLastError();
+}
 
 void launchRefineOrder(const uint32_t* keys, const uint32_t* ids, uint64_t n, uint32_t* order, hipStream_t stream)
 {
