@@ -8,7 +8,8 @@ import os
 import sys
 
 KERNELS = {"traceKernel": "traceKernel", "gatherGroupKernel": "gatherKernel", "gatherKernel": "gatherKernel",
-           "emissionKeysKernel": "emissionKeysKernel"}
+           "emissionKeysKernel": "emissionKeysKernel", "digitCountKernel": "digitCountKernel",
+           "digitScatterKernel": "digitScatterKernel", "refineOrderKernel": "refineOrderKernel"}
 
 
 def short_name(name):
