@@ -1862,7 +1862,9 @@ int32_t rt_trace(rt_tracer* tracer, const rt_trace_params* params)
             const int lights = static_cast<int>(tracer->lightCount);
             // Large passes are ordered in three steps of which only one is a pass of the radix sort
             // (rt_order.h); RT_AMD_EMISSION_SORT=radix|refine overrides the choice.
-            bool refine = n >= kRefineOrderMinimum;
+            // (beyond 2^28 ids a value of the sorted bits holds more ids than a run, and a run would then take
+            // its ids from all over that value's cells: such passes are radix-sorted over all the bits)
+            bool refine = n >= kRefineOrderMinimum && n <= (1ull << 28);
             if (const char* v = std::getenv("RT_AMD_EMISSION_SORT"))
             {
                 refine = std::strcmp(v, "radix") != 0;
