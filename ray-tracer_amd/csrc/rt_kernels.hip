@@ -1845,107 +1845,162 @@ RT_DEV Color gatherRadianceGroup(const GatherArgs& a, const GatherPoint& gp, int
                 }
             }
         }
-        const int rowsHere = static_cast<int>(rowCount - rowBase < G ? rowCount - rowBase : G);
-        for (int t = 0; t < rowsHere; ++t)
+        // One step of the walk: lane `member` has read record `at` (fetch), runs the tests and the BRDF of its
+        // record (inside: it has one), and the contributions that passed are added in lane order by every lane
+        // alike (settle).
+        typedef float Float4At4 __attribute__((ext_vector_type(4), aligned(4)));
+        struct Fetched
         {
-            const uint32_t start = G == 64 ? laneValue(myStart, t) : __shfl(myStart, t, G);
-            const uint32_t end = G == 64 ? laneValue(myEnd, t) : __shfl(myEnd, t, G);
-            if (start >= end)
+            unsigned long long key;
+            Float4At4 q0, q1, q2;
+            float q3;
+        };
+        auto fetch = [&](uint64_t at) {
+            const float* row = a.store + 13ull * at;
+            Fetched f;
+            f.key = bySlab ? a.keys[at] : 0ull;
+            f.q0 = *reinterpret_cast<const Float4At4*>(row);
+            f.q1 = *reinterpret_cast<const Float4At4*>(row + 4);
+            f.q2 = *reinterpret_cast<const Float4At4*>(row + 8);
+            f.q3 = row[12];
+            return f;
+        };
+        auto settle = [&](const Fetched& f, bool inside) {
+            const unsigned long long key = f.key;
+            const Float4At4 q0 = f.q0, q1 = f.q1, q2 = f.q2;
+            const float q3 = f.q3;
+            bool passes = inside;
+            if (passes && bySlab)
             {
-                continue;  // the same for every lane of the group
+                const int64_t kx = keyCellX(a.layout, key);
+                passes = kx >= x0 && kx <= x1;
             }
-            for (uint64_t base = start;; base += G)
+            Color contribution = black;
+            if (passes)
             {
-                typedef float Float4At4 __attribute__((ext_vector_type(4), aligned(4)));
-                const uint64_t j = base + static_cast<uint64_t>(member);
-                const bool inside = j < end;
-                const uint64_t at = inside ? j : end - 1;
-                const float* row = a.store + 13ull * at;
-                const unsigned long long key = bySlab ? a.keys[at] : 0ull;
-                const Float4At4 q0 = *reinterpret_cast<const Float4At4*>(row);
-                const Float4At4 q1 = *reinterpret_cast<const Float4At4*>(row + 4);
-                const Float4At4 q2 = *reinterpret_cast<const Float4At4*>(row + 8);
-                const float q3 = row[12];
-                const bool beyond = !inside;
-                bool passes = !beyond;
-                if (passes && bySlab)
+                const double ddx = static_cast<double>(q0.x) - position.x;
+                const double ddy = static_cast<double>(q0.y) - position.y;
+                const double ddz = static_cast<double>(q0.z) - position.z;
+                passes = ddx * ddx + ddy * ddy + ddz * ddz <= r2;
+            }
+            if (passes)
+            {
+                const float time = q2.y;
+                if (!__builtin_isinf(time) || time < 0.0f)  // +inf marks a timeless (emitter) deposit
                 {
-                    const int64_t kx = keyCellX(a.layout, key);
-                    passes = kx >= x0 && kx <= x1;
+                    passes = !(__builtin_fabsf(time - gp.sampleTime) > a.timeHalfWindow);
                 }
-                Color contribution = black;
-                if (passes)
+            }
+            if (passes)
+            {
+                const Vec dn = mk(q1.z, q1.w, q2.x);
+                const Color power{q2.z, q2.w, q3};
+                if (isEmitter)
                 {
-                    const double ddx = static_cast<double>(q0.x) - position.x;
-                    const double ddy = static_cast<double>(q0.y) - position.y;
-                    const double ddz = static_cast<double>(q0.z) - position.z;
-                    passes = ddx * ddx + ddy * ddy + ddz * ddz <= r2;
-                }
-                if (passes)
-                {
-                    const float time = q2.y;
-                    if (!__builtin_isinf(time) || time < 0.0f)  // +inf marks a timeless (emitter) deposit
-                    {
-                        passes = !(__builtin_fabsf(time - gp.sampleTime) > a.timeHalfWindow);
-                    }
-                }
-                if (passes)
-                {
-                    const Vec dn = mk(q1.z, q1.w, q2.x);
-                    const Color power{q2.z, q2.w, q3};
-                    if (isEmitter)
-                    {
-                        passes = !(dot(dn, normal) < 0.5);
-                        contribution = power;
-                    }
-                    else
-                    {
-                        const double dnLen = magnitude(dn);
-                        if (dnLen > 1e-4)
-                        {
-                            passes = !(dot(dn / dnLen, normal) < 0.5);
-                        }
-                        if (passes)
-                        {
-                            const double planeDist = dabs(dot(mk(q0.x, q0.y, q0.z) - position, normal));
-                            passes = !(planeDist > planeBand);
-                        }
-                        if (passes)
-                        {
-                            const Vec wi = neg(mk(q0.w, q1.x, q1.y));
-                            contribution = evaluateMaterial(*material, wi, wo, normal) * power;
-                        }
-                    }
-                }
-                // the group's verdicts, then the additions in record order
-                const unsigned long long passMask = __ballot(passes), beyondMask = __ballot(beyond);
-                if (G == 64)
-                {
-                    unsigned long long todo = passMask;
-                    kept += static_cast<unsigned long long>(__builtin_popcountll(todo));
-                    while (todo != 0)
-                    {
-                        const int k = __builtin_ctzll(todo);
-                        todo &= todo - 1;
-                        sum.r += laneValue(contribution.r, k);
-                        sum.g += laneValue(contribution.g, k);
-                        sum.b += laneValue(contribution.b, k);
-                    }
-                    if (beyondMask != 0) break;
+                    passes = !(dot(dn, normal) < 0.5);
+                    contribution = power;
                 }
                 else
                 {
-                    uint32_t todo = groupBits<G>(passMask, groupBase);
-                    kept += static_cast<unsigned long long>(__builtin_popcount(todo));
-                    while (todo != 0)
+                    const double dnLen = magnitude(dn);
+                    if (dnLen > 1e-4)
                     {
-                        const int k = __builtin_ctz(todo);
-                        todo &= todo - 1;
-                        sum.r += __shfl(contribution.r, k, G);
-                        sum.g += __shfl(contribution.g, k, G);
-                        sum.b += __shfl(contribution.b, k, G);
+                        passes = !(dot(dn / dnLen, normal) < 0.5);
                     }
-                    if (groupBits<G>(beyondMask, groupBase) != 0) break;
+                    if (passes)
+                    {
+                        const double planeDist = dabs(dot(mk(q0.x, q0.y, q0.z) - position, normal));
+                        passes = !(planeDist > planeBand);
+                    }
+                    if (passes)
+                    {
+                        const Vec wi = neg(mk(q0.w, q1.x, q1.y));
+                        contribution = evaluateMaterial(*material, wi, wo, normal) * power;
+                    }
+                }
+            }
+            // the group's verdicts, then the additions in record order
+            const unsigned long long passMask = __ballot(passes);
+            if (G == 64)
+            {
+                unsigned long long todo = passMask;
+                kept += static_cast<unsigned long long>(__builtin_popcountll(todo));
+                while (todo != 0)
+                {
+                    const int k = __builtin_ctzll(todo);
+                    todo &= todo - 1;
+                    sum.r += laneValue(contribution.r, k);
+                    sum.g += laneValue(contribution.g, k);
+                    sum.b += laneValue(contribution.b, k);
+                }
+            }
+            else
+            {
+                uint32_t todo = groupBits<G>(passMask, groupBase);
+                kept += static_cast<unsigned long long>(__builtin_popcount(todo));
+                while (todo != 0)
+                {
+                    const int k = __builtin_ctz(todo);
+                    todo &= todo - 1;
+                    sum.r += __shfl(contribution.r, k, G);
+                    sum.g += __shfl(contribution.g, k, G);
+                    sum.b += __shfl(contribution.b, k, G);
+                }
+            }
+        };
+        if (G == 64)
+        {
+            // A wave per pixel: the rows' records are laid end to end and taken 64 at a time, whichever rows
+            // they belong to — a footprint's rows hold a few records each, and walked row by row every row
+            // would cost a trip to memory for a handful of busy lanes.  The order of the records, and with it
+            // of the additions, is the same: rows in their order, a row's records in theirs.
+            const uint32_t length = myEnd > myStart ? myEnd - myStart : 0u;
+            uint32_t upTo = length;  // records of this lane's row and the rows before it
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1)
+            {
+                const uint32_t before = __shfl_up(upTo, d, 64);
+                if (member >= d) upTo += before;
+            }
+            const uint32_t total = laneValue(upTo, 63);
+            // the record at `place` of the rows laid end to end (a lane beyond the end looks at the last one)
+            auto recordAt = [&](uint32_t base) {
+                const uint32_t mine = base + static_cast<uint32_t>(member);
+                const uint32_t place = mine < total ? mine : total - 1;
+                // the row that holds the place: the first whose running total exceeds it
+                uint32_t holder = 0;
+#pragma unroll
+                for (uint32_t s = 32; s > 0; s >>= 1)
+                {
+                    const uint32_t edge = __shfl(upTo, static_cast<int>(holder + s - 1), 64);
+                    if (edge <= place) holder += s;
+                }
+                const uint32_t holderUpTo = __shfl(upTo, static_cast<int>(holder), 64);
+                const uint32_t holderEnd = __shfl(myEnd, static_cast<int>(holder), 64);
+                return static_cast<uint64_t>(holderEnd - (holderUpTo - place));
+            };
+            for (uint32_t base = 0; base < total; base += 64)
+            {
+                settle(fetch(recordAt(base)), base + static_cast<uint32_t>(member) < total);
+            }
+        }
+        else
+        {
+            const int rowsHere = static_cast<int>(rowCount - rowBase < G ? rowCount - rowBase : G);
+            for (int t = 0; t < rowsHere; ++t)
+            {
+                const uint32_t start = __shfl(myStart, t, G);
+                const uint32_t end = __shfl(myEnd, t, G);
+                if (start >= end)
+                {
+                    continue;  // the same for every lane of the group
+                }
+                for (uint64_t base = start;; base += G)
+                {
+                    const uint64_t j = base + static_cast<uint64_t>(member);
+                    const bool inside = j < end;
+                    settle(fetch(inside ? j : end - 1), inside);
+                    if (groupBits<G>(__ballot(!inside), groupBase) != 0) break;
                 }
             }
         }
