@@ -1774,6 +1774,59 @@ __global__ __launch_bounds__(kGatherThreads) void gatherKernel(const GatherArgs 
 // consecutive records of a row of cells, each lane runs the tests and the BRDF of its record, and
 // the contributions that passed are then added in record order by every lane of the group alike —
 // the additions, and with them the rounding, are exactly those of the one-lane walk.
+// sum += the contributions of the lanes in passMask, one after the other in lane order (the rounding of
+// a walk that adds record by record), for a whole wave at once.  The lanes that passed hand their
+// contributions to lanes 0 .. passed - 1 in their order (one permutation through the LDS crossbar);
+// lane 0 adds the sum so far to its own; then every lane adds its contribution to its lower
+// neighbour's running sum (a DPP shift by one lane, three instructions a step for the three colours):
+// after step k lanes 0 .. k hold the sums a serial walk would hold after their records, and steps
+// beyond the last change none of them.  Lane passed - 1 ends with the new sum.  (Reading the lanes one
+// by one into scalar registers costs eight instructions a record.)
+RT_DEV void orderedAdd(unsigned long long passMask, uint32_t passed, const Color& contribution, Color* sum)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    const bool passes = ((passMask >> lane) & 1ull) != 0;
+    const uint32_t below = lanesBelow(passMask);
+    // those that passed go to the front in their order, the others behind them in theirs: a permutation
+    const int target = static_cast<int>(passes ? below : passed + (lane - below)) * 4;
+    float r = __builtin_bit_cast(float, __builtin_amdgcn_ds_permute(target, __builtin_bit_cast(int, contribution.r)));
+    float g = __builtin_bit_cast(float, __builtin_amdgcn_ds_permute(target, __builtin_bit_cast(int, contribution.g)));
+    float b = __builtin_bit_cast(float, __builtin_amdgcn_ds_permute(target, __builtin_bit_cast(int, contribution.b)));
+    if (lane == 0)
+    {
+        r = sum->r + r;
+        g = sum->g + g;
+        b = sum->b + b;
+    }
+    float runR = r, runG = g, runB = b;
+    // four steps a trip (a lane without a lower neighbour keeps what it has); the s_nop covers the two wait
+    // states between a vector write and a DPP read of the same register, which later steps get from the
+    // two instructions in between
+    for (uint32_t step = 1; step < passed; step += 4)
+    {
+        asm volatile(
+            "s_nop 1\n"
+            "v_add_f32_dpp %0, %0, %3 wave_shr:1 row_mask:0xf bank_mask:0xf\n"
+            "v_add_f32_dpp %1, %1, %4 wave_shr:1 row_mask:0xf bank_mask:0xf\n"
+            "v_add_f32_dpp %2, %2, %5 wave_shr:1 row_mask:0xf bank_mask:0xf\n"
+            "v_add_f32_dpp %0, %0, %3 wave_shr:1 row_mask:0xf bank_mask:0xf\n"
+            "v_add_f32_dpp %1, %1, %4 wave_shr:1 row_mask:0xf bank_mask:0xf\n"
+            "v_add_f32_dpp %2, %2, %5 wave_shr:1 row_mask:0xf bank_mask:0xf\n"
+            "v_add_f32_dpp %0, %0, %3 wave_shr:1 row_mask:0xf bank_mask:0xf\n"
+            "v_add_f32_dpp %1, %1, %4 wave_shr:1 row_mask:0xf bank_mask:0xf\n"
+            "v_add_f32_dpp %2, %2, %5 wave_shr:1 row_mask:0xf bank_mask:0xf\n"
+            "v_add_f32_dpp %0, %0, %3 wave_shr:1 row_mask:0xf bank_mask:0xf\n"
+            "v_add_f32_dpp %1, %1, %4 wave_shr:1 row_mask:0xf bank_mask:0xf\n"
+            "v_add_f32_dpp %2, %2, %5 wave_shr:1 row_mask:0xf bank_mask:0xf\n"
+            "s_nop 1\n"
+            : "+v"(runR), "+v"(runG), "+v"(runB)
+            : "v"(r), "v"(g), "v"(b));
+    }
+    sum->r = laneValue(runR, static_cast<int>(passed - 1));
+    sum->g = laneValue(runG, static_cast<int>(passed - 1));
+    sum->b = laneValue(runB, static_cast<int>(passed - 1));
+}
+
 template <int G>
 RT_DEV uint32_t groupBits(unsigned long long waveMask, int groupBase)
 {
@@ -1923,15 +1976,11 @@ RT_DEV Color gatherRadianceGroup(const GatherArgs& a, const GatherPoint& gp, int
             const unsigned long long passMask = __ballot(passes);
             if (G == 64)
             {
-                unsigned long long todo = passMask;
-                kept += static_cast<unsigned long long>(__builtin_popcountll(todo));
-                while (todo != 0)
+                const uint32_t passed = static_cast<uint32_t>(__builtin_popcountll(passMask));
+                kept += passed;
+                if (passed != 0)
                 {
-                    const int k = __builtin_ctzll(todo);
-                    todo &= todo - 1;
-                    sum.r += laneValue(contribution.r, k);
-                    sum.g += laneValue(contribution.g, k);
-                    sum.b += laneValue(contribution.b, k);
+                    orderedAdd(passMask, passed, contribution, &sum);
                 }
             }
             else
