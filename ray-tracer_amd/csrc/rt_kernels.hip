@@ -1418,7 +1418,9 @@ RT_DEV bool directoryEntries(const GatherArgs& a, int64_t x0, int64_t x1, int64_
 }
 
 // testing::gatherRadiance, reference src/ProbeGather.cpp:596-728, for one gather point.
-constexpr int kGatherThreads = 256;  // threads of a gather block
+// (a wave a block: a block's place on the chip is free again when its last wave ends, and the pixels of a
+// 256-thread block end far apart: MirrorKnot4k's gather 16.0 -> 14.4 ms)
+constexpr int kGatherThreads = 64;   // threads of a gather block
 constexpr int kGatherQueue = 16;     // records a lane of the one-lane gather queues before it settles them
 
 // queue: the lane's column of the block's [kGatherQueue][kGatherThreads] words of LDS
@@ -1461,16 +1463,18 @@ RT_DEV Color gatherRadiance(const GatherArgs& a, const GatherPoint& gp, uint32_t
     unsigned long long kept = 0;
     // Rows of cells along x are contiguous in key order; when the cube is wide, whole z slabs are
     // scanned and filtered instead of searching every row.  Where the rows start in the key list is
-    // looked up for nine rows at a time (the whole neighbourhood of a footprint that fits a cell), the
-    // nine binary searches advancing in step: their reads, chains of dependent round trips each, are in
+    // looked up for three rows at a time (a slab of the neighbourhood of a footprint that fits a cell), the
+    // three binary searches advancing in step: their reads, chains of dependent round trips each, are in
     // flight together, and so are the reads of every row's first key, which tell the empty rows (most of
     // them, on a thin store) from the ones worth a walk.  The rows are then walked in the reference's
-    // order (z outside, y inside, store order within a cell).
+    // order (z outside, y inside, store order within a cell).  (Nine rows in step and eight records a
+    // read keep more reads in flight per lane but cost 212 registers, two waves per SIMD; three and four
+    // fit three waves, which hides more: MirrorKnot4k's gather 14.4 -> 13.0 ms.)
     const bool bySlab = (y1 - y0) > 16;
     // (a footprint spans at most 2^21 cells along an axis and fewer than 17 rows per slab: 32-bit row numbers)
     const int rowsPerSlab = bySlab ? 1 : static_cast<int>(y1 - y0 + 1);
     const int rowCount = static_cast<int>(z1 - z0 + 1) * rowsPerSlab;
-    constexpr int kRows = 9;
+    constexpr int kRows = 3;
     // Records that lie within the footprint (and the shutter's window) wait in the lane's queue, in
     // their order, and go through the remaining tests and the BRDF together: were each taken where
     // it is found, the wave would run the BRDF for nearly every record any of its lanes looks at,
@@ -1636,7 +1640,7 @@ RT_DEV Color gatherRadiance(const GatherArgs& a, const GatherPoint& gp, uint32_t
             // together before any test looks at one.  Only what the first tests need is read here (the
             // key where slabs are filtered, position and time): few records of a
             // neighbourhood lie within the footprint, and those are queued for settle().
-            constexpr uint32_t kChunk = 8;
+            constexpr uint32_t kChunk = 4;
             for (uint32_t base = lo[k]; base < hi[k]; base += kChunk)
             {
                 unsigned long long key[kChunk];
@@ -2636,7 +2640,8 @@ void launchGather(const GatherArgs& args, int lanesPerPixel, int computeUnits, h
     if (args.pixels <= 0) return;
     if (lanesPerPixel >= 64)
     {
-        hipLaunchKernelGGL(gatherGroupKernel<64>, dim3(gridFor(args.pixels * 64)), dim3(256), 0, stream, args);
+        // (a wave a block, as for the one-lane kernel)
+        hipLaunchKernelGGL(gatherGroupKernel<64>, dim3(static_cast<uint32_t>(args.pixels)), dim3(64), 0, stream, args);
     }
     else if (lanesPerPixel >= 8)
     {
@@ -2644,7 +2649,8 @@ void launchGather(const GatherArgs& args, int lanesPerPixel, int computeUnits, h
     }
     else
     {
-        hipLaunchKernelGGL(gatherKernel, dim3(gridFor(args.pixels)), dim3(kGatherThreads), 0, stream, args);
+        hipLaunchKernelGGL(gatherKernel, dim3(static_cast<uint32_t>((args.pixels + kGatherThreads - 1) / kGatherThreads)), dim3(kGatherThreads), 0,
+                           stream, args);
         if (args.heavyThreshold != 0)
         {
             // the pixels left over, a wave each: a grid that fills the chip takes them in turns
@@ -2652,7 +2658,7 @@ void launchGather(const GatherArgs& args, int lanesPerPixel, int computeUnits, h
             rest.heavyThreshold = 0;
             rest.pixelList = args.heavyPixels;
             rest.pixelListCount = args.heavyCount;
-            hipLaunchKernelGGL(gatherGroupKernel<64>, dim3(static_cast<uint32_t>(std::max(1, computeUnits) * 8)), dim3(256), 0, stream,
+            hipLaunchKernelGGL(gatherGroupKernel<64>, dim3(static_cast<uint32_t>(std::max(1, computeUnits) * 32)), dim3(64), 0, stream,
                                rest);
         }
     }
