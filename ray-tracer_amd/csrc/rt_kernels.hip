@@ -2523,16 +2523,19 @@ void launchGatherCount(const SceneView& scene, int32_t camera, int32_t stride, i
                        unsigned long long* stats, hipStream_t stream)
 {
     if (pixels <= 0) return;
-    hipLaunchKernelGGL(gatherCountKernel, dim3(gridFor(pixels)), dim3(256), stackBytes(scene, 256), stream, scene, camera, stride, counts,
-                       stats);
+    // a wave a block: pixels of a block end far apart (some rays leave the scene at once, others pass glass
+    // and mirrors), and a block's place is free again only when its last wave ends (MirrorKnot4k's probe
+    // pass 19.2 -> 12.0 ms)
+    hipLaunchKernelGGL(gatherCountKernel, dim3(static_cast<uint32_t>((pixels + 63) / 64)), dim3(64), stackBytes(scene, 64), stream, scene,
+                       camera, stride, counts, stats);
 }
 
 void launchGatherWrite(const SceneView& scene, int32_t camera, int32_t stride, int64_t pixels, const uint32_t* counts,
                        const uint64_t* offsets, GatherPoint* out, hipStream_t stream)
 {
     if (pixels <= 0) return;
-    hipLaunchKernelGGL(gatherWriteKernel, dim3(gridFor(pixels)), dim3(256), stackBytes(scene, 256), stream, scene, camera, stride, counts,
-                       offsets, out);
+    hipLaunchKernelGGL(gatherWriteKernel, dim3(static_cast<uint32_t>((pixels + 63) / 64)), dim3(64), stackBytes(scene, 64), stream, scene,
+                       camera, stride, counts, offsets, out);
 }
 
 hipError_t buildCellDirectory(void* scratch, size_t* scratchBytes, const unsigned long long* sortedKeys, uint64_t indexed,
