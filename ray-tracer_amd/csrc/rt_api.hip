@@ -2024,11 +2024,12 @@ int32_t rt_trace(rt_tracer* tracer, const rt_trace_params* params)
             // a wave whose lanes stand in different corners of the scene: four long runs per wave.  A launch
             // whose photons all make one bounce and leave can take shorter runs, so that the waves end
             // together: sixteen per wave for parked photons (their bounces are the expensive, divergent
-            // ones: MirrorKnot4k 24.8 -> 20.7 ms), eight for the emission (short runs cost a cheap scene
-            // more than balance gains it: CornellBox prefers four, a 25 M share of Bombardment sixteen).
+            // ones: MirrorKnot4k 24.8 -> 20.7 ms), eight for the emission of fewer than 16 Mi photons (short runs
+            // cost a cheap scene more than balance gains it: CornellBox with its 10 M prefers four), sixteen
+            // for larger ones (MirrorKnot4k's 20 M: 21.1 -> 20.7 ms, a 25 M share of Bombardment 3.18 -> 3.06).
             // (RT_AMD_RUNS_PER_WAVE overrides.)
             const bool oneTrip = level < levels || (levels > 0 && levels >= tracer->settings.bounce_threshold);
-            const int runsPerWave = !oneTrip ? 4 : (level == 0 ? 8 : 16);
+            const int runsPerWave = !oneTrip ? 4 : ((level == 0 && work < (16ull << 20)) ? 8 : 16);
             const int blocks = scheduleLaunch(launch, work, residentBlocks, level == 0 || sortedLevel, runsPerWave);
             if (level > 0) launch.claimStride = 1;
             const auto levelStart = std::chrono::steady_clock::now();
