@@ -1560,8 +1560,42 @@ RT_DEV Color gatherRadiance(const GatherArgs& a, const GatherPoint& gp, uint32_t
             {
                 widest = max(widest, hi[k] - lo[k]);
             }
+            // Short ranges (a directory of rows over a thin store leaves a few records a row): their keys are
+            // read in one go and counted against the row's first and last key, one round trip instead of the
+            // two searches' four.
+            constexpr uint32_t kShort = 4;
+            if (widest != 0 && widest <= kShort)
+            {
+                unsigned long long near[kRows][kShort];
+#pragma unroll
+                for (int k = 0; k < kRows; ++k)
+                {
+#pragma unroll
+                    for (uint32_t u = 0; u < kShort; ++u)
+                    {
+                        const uint32_t at = lo[k] + u < hi[k] ? lo[k] + u : lo[k];
+                        near[k][u] = a.keys[at < a.indexed ? at : a.indexed - 1];
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < kRows; ++k)
+                {
+                    const unsigned long long first = firstKey(k), last = lastKey(k);
+                    uint32_t below = 0, within = 0;  // keys ascend: those below the first, those up to the last
+#pragma unroll
+                    for (uint32_t u = 0; u < kShort; ++u)
+                    {
+                        const bool there = lo[k] + u < hi[k];
+                        below += (there && near[k][u] < first) ? 1u : 0u;
+                        within += (there && near[k][u] <= last) ? 1u : 0u;
+                    }
+                    hi[k] = lo[k] + within;
+                    lo[k] = lo[k] + below;
+                }
+                widest = 0;  // (no search below)
+            }
             int steps = 0;
-            while ((1u << steps) <= widest) ++steps;
+            while (widest != 0 && (1u << steps) <= widest) ++steps;
             uint32_t end[kRows];
 #pragma unroll
             for (int k = 0; k < kRows; ++k)
@@ -1592,7 +1626,7 @@ RT_DEV Color gatherRadiance(const GatherArgs& a, const GatherPoint& gp, uint32_t
 #pragma unroll
             for (int k = 0; k < kRows; ++k)
             {
-                hi[k] = lo[k];
+                hi[k] = steps > 0 ? lo[k] : hi[k];
             }
             for (int step = 0; step < steps; ++step)
             {
