@@ -1,5 +1,6 @@
 """Copy the results of one tools/profile.sh run (gpurun_out/<tag>/) into profiles/:
-    python tools/publish_profile.py <tag> <round>
+    python tools/publish_profile.py <tag> <round> [suffix]
+(suffix: appended to the file names, for a run at another photon count than the scene's own)
 writes profiles/<round>_<workload>_kernel_stats.csv, _bench.json, _pmc.csv and refreshes the workload's entry
 of profiles/counters.json, the per-pass counter record bench.py's roofline reads."""
 import glob
@@ -11,7 +12,7 @@ import sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def main(tag, rnd):
+def main(tag, rnd, suffix=""):
     src = os.path.join(REPO, "gpurun_out", tag)
     dst = os.path.join(REPO, "profiles")
     bench = json.load(open(os.path.join(src, "bench.json")))
@@ -19,7 +20,7 @@ def main(tag, rnd):
     photons = bench["config"]["photons_per_light"] * bench["config"]["lights"]
     # a scene profiled with the sink that is not its own keeps both sets of files
     own = bench["config"].get("scene_sink", sink)
-    name = workload if sink == own else f"{workload}_{sink}"
+    name = (workload if sink == own else f"{workload}_{sink}") + suffix
     stem = os.path.join(dst, f"{rnd}_{name}")
     stats = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)[0]
     shutil.copy(stats, stem + "_kernel_stats.csv")
@@ -29,7 +30,8 @@ def main(tag, rnd):
     start = next(i for i, line in enumerate(lines) if line.startswith("kernel,counter,value"))
     with open(stem + "_pmc.csv", "w") as f:
         f.write("# rocprofv3 --pmc passes (one counter group per run, tools/profile.sh) of: python3 bench.py --scene "
-                f"scenes/{workload}.json --sink {sink} --steps 1 --warmup 0 --no-cpu-baseline\n")
+                f"scenes/{workload}.json --sink {sink} --photons {bench['config']['photons_per_light']} --steps 1 --warmup 0 "
+                "--no-cpu-baseline\n")
         f.write(f"# one step = one photon pass of {photons} photons ({sink} sink) and its gather; counters are summed over "
                 "a kernel's launches in the step; FETCH_SIZE / WRITE_SIZE are in KiB as rocprofv3 reports them, uncorrected\n")
         f.write("\n".join(lines[start:]) + "\n")
@@ -76,4 +78,4 @@ def main(tag, rnd):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "r02")
+    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "r02", sys.argv[3] if len(sys.argv) > 3 else "")
