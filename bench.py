@@ -164,6 +164,9 @@ def main():
                     help="always: set up the process group and run the all-reduces with one rank too (exercises the RCCL path on one GPU)")
     ap.add_argument("--share-device", action="store_true",
                     help="rehearsal: every rank uses GPU 0 (with --backend gloo)")
+    ap.add_argument("--store-share", type=int, default=0,
+                    help="rehearsal on one GPU of one rank's step among this many: with --photons <share> the store is held "
+                         "to the part of it a rank among N keeps")
     ap.add_argument("--cpu-photons", type=int, default=40_000_000,
                     help="photons per light of the CPU baseline sample (about 20 s of CPU work)")
     args = ap.parse_args()
@@ -241,6 +244,11 @@ def main():
         buffers.append(t)
 
     first, count = parallel.shard_range(photons, rank, world)
+    store_ranks = world if world > 1 else max(1, args.store_share)
+    if store_ranks > 1 and sink == "probe":
+        # the frame has ONE store: a rank keeps the emitter deposits (rank 0) plus 1/N of the rest
+        tracer.reset()
+        frame.share_store(tracer, setup["store_capacity"], max(gather_cell * 0.5, 1e-6), rank, store_ranks)
     sink_mode = {"none": rt.tracer.SINK_NONE, "probe": rt.tracer.SINK_PROBE, "splat": rt.tracer.SINK_SPLAT}[sink]
     whole_frame = args.step == "frame"
 

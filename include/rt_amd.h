@@ -136,6 +136,17 @@ int32_t rt_set_probes(rt_tracer* tracer, const double* probes, uint64_t n, doubl
 int32_t rt_set_probes_from_cameras(rt_tracer* tracer, double cell_size, double keep_radius, uint64_t records_per_probe,
                                    uint64_t max_store_capacity, uint64_t* probe_count, uint64_t* store_capacity);
 
+/* One rank's share of the BounceStore when a frame's photons are spread over several GPUs: from
+ * now on the store takes `max_records` records in all (0, or more than the capacity given to
+ * rt_set_probes*: the whole capacity; rt_set_probes* sets it back to the whole).  The reference
+ * has ONE store per frame whose capacity is a setting of the scene (reference
+ * src/Renderer.cpp:382-390, src/BounceStore.cpp:21-33: an append beyond it is dropped and
+ * counted); ranks that each kept a whole capacity would keep up to N times the records of the
+ * one-GPU frame, and a frame that overflows would come out that much brighter.  A sharded frame
+ * therefore gives rank r the emitter deposits (rank 0 only) plus 1/N of the rest of the capacity.
+ * Call with a store that holds no more than `max_records` records. */
+int32_t rt_set_store_limit(rt_tracer* tracer, uint64_t max_records);
+
 /* ProbeGather::depositEmitters (reference src/ProbeGather.cpp:464-550) on the device: the lit
  * face of every area light is tiled with cell-centred deposits `deposit_spacing` apart, those
  * within the keep radius of a probe are appended to the store as timeless records carrying the

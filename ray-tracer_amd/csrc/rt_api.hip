@@ -208,7 +208,8 @@ struct rt_tracer
     DeviceArray<rtd::NearEntry> nearEntries;
     rtd::ProbeView probeView{};
     DeviceArray<float> storeRecords;
-    uint64_t storeCapacity = 0;
+    uint64_t storeCapacity = 0;   // records the store takes (rt_set_store_limit may hold it below what is allocated)
+    uint64_t storeAllocated = 0;  // records the store has room for
 
     // sink B
     bool splatSet = false;
@@ -1411,6 +1412,7 @@ void setProbes(rt_tracer* tracer, const double* probes, bool probesOnDevice, uin
     const double invCellSize = 1.0 / cellSize;
     const double keepRadius = keep_radius > 0.0 ? keep_radius : 0.0;
     tracer->storeCapacity = store_capacity;
+    tracer->storeAllocated = store_capacity;
     tracer->storeVersion += 1;
     tracer->storeRecords.allocate(static_cast<size_t>(store_capacity) * 13);
     // the usual case (one cell of reach, coordinates that pack) is built on the device
@@ -1537,6 +1539,32 @@ int32_t rt_set_probes_from_cameras(rt_tracer* tracer, double cell_size, double k
         setProbes(tracer, positions.ptr, true, total, cell_size, keep_radius, capacity);
         if (probe_count != nullptr) *probe_count = total;
         if (store_capacity != nullptr) *store_capacity = capacity;
+    });
+}
+
+int32_t rt_set_store_limit(rt_tracer* tracer, uint64_t max_records)
+{
+    return guarded([&]() {
+        require(tracer != nullptr, "tracer is null");
+        if (!tracer->probesSet)
+        {
+            throw ApiError(RT_ERR_STATE, "rt_set_probes must be called before rt_set_store_limit");
+        }
+        activate(tracer);
+        const uint64_t limit = (max_records == 0 || max_records > tracer->storeAllocated) ? tracer->storeAllocated : max_records;
+        // the cursor counts the appends that were tried: a store that was over its old limit holds that limit
+        unsigned long long cursor = 0;
+        check(hipMemcpyAsync(&cursor, tracer->scalars.ptr + 1, sizeof(cursor), hipMemcpyDeviceToHost, tracer->stream),
+              "hipMemcpyAsync store cursor");
+        check(hipStreamSynchronize(tracer->stream), "hipStreamSynchronize");
+        const uint64_t held = std::min<uint64_t>(cursor, tracer->storeCapacity);
+        if (held > limit)
+        {
+            throw ApiError(RT_ERR_STATE, "rt_set_store_limit: the store holds " + std::to_string(held) + " records, more than the limit of " +
+                                             std::to_string(limit));
+        }
+        tracer->storeCapacity = limit;
+        tracer->storeVersion += 1;
     });
 }
 

@@ -34,14 +34,29 @@ def prepare_sinks(rt, scene, tracer, sink):
     return info
 
 
+def share_store(tracer, capacity, emitter_spacing, rank, world):
+    """Limit this rank's store to its share of the frame's one store (parallel.store_share).  Every
+    rank lays down the emitter deposits once to learn how many there are (they depend on the probes
+    only, which the ranks share); they stay in rank 0's store and leave the others'.  Call after
+    set_probes* and reset; returns the number of emitter deposits."""
+    from . import parallel
+
+    _, emitters = tracer.deposit_emitters(emitter_spacing)
+    if rank != 0:
+        tracer.reset()
+    tracer.set_store_limit(parallel.store_share(capacity, emitters, rank, world))
+    return emitters
+
+
 def render_frame(rt, scene, tracer, buffers, rank=0, world=1, dist=None):
     """One frame on this rank's GPU, reduced over the ranks: Renderer::renderFrame (reference
     src/Renderer.cpp:222-700) with the photon indices sharded.
 
     `buffers[c]` is the torch tensor bound as camera c's buffer (bind_camera_buffer), so that the
     collective reduces it in place.  Probe-gather mode: every rank runs the probe pass and builds
-    the same keep-test index, rank 0 alone deposits the emitter faces (they must enter the sum
-    once), every rank traces its share into its own store and gathers it into its own camera
+    the same keep-test index, rank 0 alone keeps the emitter faces' deposits (they must enter the sum
+    once), every rank traces its share into its own store — limited to its part of the frame's one
+    store, so that an overflowing frame keeps as many records as on one GPU — and gathers it into its own camera
     buffers — the gather is linear in the deposits (reference src/ProbeGather.cpp:653-727) — and
     one all-reduce(sum) per camera makes the frame.  Splat mode: the trace accumulates into the
     buffers directly, then the same all-reduce.  Returns the reduced counters."""
@@ -55,9 +70,12 @@ def render_frame(rt, scene, tracer, buffers, rank=0, world=1, dist=None):
                  if scene.desc.cameras[c].bounce_filter < 0 and scene.desc.cameras[c].light_filter < 0]
     if scene.settings.use_probe_gather:
         cell = d["scene_depth_footprint"] if d["scene_depth_footprint"] > 0.0 else d["cell_size"]
-        tracer.set_probes_from_cameras(d["keep_radius"], d["keep_radius"], 256, int(scene.settings.bounce_store_capacity))
+        _, capacity = tracer.set_probes_from_cameras(d["keep_radius"], d["keep_radius"], 256,
+                                                     int(scene.settings.bounce_store_capacity))
         tracer.reset()
-        if rank == 0:
+        if world > 1:
+            share_store(tracer, capacity, max(cell * 0.5, 1e-6), rank, world)  # (leaves rank 0's emitter deposits in)
+        elif rank == 0:
             tracer.deposit_emitters(max(cell * 0.5, 1e-6))
         if count > 0:  # an empty share traces nothing (a count of 0 would mean "all the rest")
             tracer.trace(sink_mode=rt.tracer.SINK_PROBE, first_photon=first, photon_count=count)

@@ -62,6 +62,17 @@ struct Communicators
     }
 };
 
+// Records rank `rank` among `world` may keep of the frame's one bounce store (reference
+// src/Renderer.cpp:382-390): the emitter deposits, which are rank 0's, plus an equal part of the rest,
+// so that a frame whose store overflows keeps as many records on several GPUs as on one.
+uint64_t storeShareOf(uint64_t capacity, uint64_t emitterRecords, int rank, int world)
+{
+    const uint64_t emitters = std::min(emitterRecords, capacity);
+    const uint64_t rest = capacity - emitters;
+    const uint64_t ranks = static_cast<uint64_t>(std::max(1, world));
+    return std::max<uint64_t>(1, (rank == 0 ? emitters : 0) + (rest + ranks - 1) / ranks);
+}
+
 // photon indices [first, first + count) of rank `rank` among `world`
 void shardOf(size_t perLight, int rank, int world, size_t* first, size_t* count)
 {
@@ -93,6 +104,14 @@ std::string otherRankFrame(const rt_scene* scene, const FrameDerived& derived, i
             uint64_t probeCount = 0, capacity = 0;
             check(rt_set_probes_from_cameras(tracer.ptr, derived.keepRadius, derived.keepRadius, 256,
                                              scene->settings.bounce_store_capacity, &probeCount, &capacity));
+            // the emitter deposits are laid down once to learn their number (rank 0 keeps its own), then
+            // the store is held to this rank's share
+            check(rt_reset(tracer.ptr));
+            const double emitterGatherCell = derived.sceneDepthFootprint > 0.0 ? derived.sceneDepthFootprint : derived.cellSize;
+            uint64_t emitterKept = 0;
+            check(rt_deposit_emitters(tracer.ptr, std::max(emitterGatherCell * 0.5, 1e-6), nullptr, &emitterKept));
+            check(rt_reset(tracer.ptr));
+            check(rt_set_store_limit(tracer.ptr, storeShareOf(capacity, emitterKept, rank, world)));
         }
         else
         {
@@ -293,6 +312,10 @@ RenderResult renderFrame(const LoadedScene& scene, ProgressCallback progress, Pr
         uint64_t emitterSamples = 0, emitterKept = 0;
         check(rt_deposit_emitters(tracer.ptr, std::max(emitterGatherCell * 0.5, 1e-6), &emitterSamples, &emitterKept));
         result.emitterDepositsKept = emitterKept;
+        if (world > 1)
+        {
+            check(rt_set_store_limit(tracer.ptr, storeShareOf(capacity, emitterKept, 0, world)));
+        }
         stage("emitter deposits");
     }
     else

@@ -18,6 +18,18 @@ def shard_range(photons, rank, world):
     return lo, hi - lo
 
 
+def store_share(capacity, emitter_records, rank, world):
+    """Records rank `rank` of `world` may keep of a frame's ONE bounce store of `capacity` records
+    (reference src/Renderer.cpp:382-390): the emitter deposits, which go in first and are rank 0's,
+    plus an equal part of what they leave.  The parts add up to the capacity (rounded up per rank),
+    so a frame whose store overflows keeps as many records on N GPUs as on one."""
+    if world < 1 or not 0 <= rank < world:
+        raise ValueError(f"bad rank {rank} of {world}")
+    emitters = min(int(emitter_records), int(capacity))
+    rest = int(capacity) - emitters
+    return max(1, (emitters if rank == 0 else 0) + (rest + world - 1) // world)
+
+
 def all_reduce_sum(tensors, dist=None):
     """Sum each tensor over all ranks in place (RCCL on GPUs, gloo in CPU tests)."""
     if dist is None:

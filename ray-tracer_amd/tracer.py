@@ -45,6 +45,7 @@ _SIGNATURES = {
     "rt_set_probes": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_double, C.c_double, C.c_uint64]),
     "rt_set_probes_from_cameras": (C.c_int32, [C.c_void_p, C.c_double, C.c_double, C.c_uint64, C.c_uint64,
                                                 C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "rt_set_store_limit": (C.c_int32, [C.c_void_p, C.c_uint64]),
     "rt_deposit_emitters": (C.c_int32, [C.c_void_p, C.c_double, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "rt_set_splat": (C.c_int32, [C.c_void_p, C.c_double, C.c_double, C.c_uint64]),
     "rt_bind_camera_buffer": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p]),
@@ -188,6 +189,10 @@ class Tracer:
         _check(tracer_lib().rt_set_probes_from_cameras(self._handle, cell_size, keep_radius, records_per_probe,
                                                        max_store_capacity, C.byref(probes), C.byref(capacity)))
         return int(probes.value), int(capacity.value)
+
+    def set_store_limit(self, max_records):
+        """One rank's share of the store (0: its whole capacity); see rt_set_store_limit."""
+        _check(tracer_lib().rt_set_store_limit(self._handle, C.c_uint64(max_records)))
 
     def deposit_emitters(self, deposit_spacing):
         """Emitter-face deposits straight into the store; returns (generated, kept)."""

@@ -23,6 +23,8 @@ def main():
     scene.settings.photons_per_light = photons
     scene.settings.use_probe_gather = 1 if probe_gather else 0
     scene.settings.seeded, scene.settings.seed = 1, 9
+    if len(sys.argv) > 5:
+        scene.settings.bounce_store_capacity = int(sys.argv[5])  # a store small enough to overflow
     device = torch.device("cuda", 0)
     tracer = rt.Tracer(scene, device=0)
     buffers = []

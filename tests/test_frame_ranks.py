@@ -15,8 +15,10 @@ pytestmark = pytest.mark.gpu
 WORKER = os.path.join(REPO, "tests", "frame_ranks_worker.py")
 
 
-def render(ranks, scene, photons, probe_gather, out):
+def render(ranks, scene, photons, probe_gather, out, store_capacity=None):
     args = [WORKER, os.path.join(REPO, scene), str(photons), "1" if probe_gather else "0", out]
+    if store_capacity is not None:
+        args.append(str(store_capacity))
     if ranks == 1:
         cmd = [sys.executable] + args
     else:
@@ -54,3 +56,25 @@ def test_more_ranks_than_photons(tmp_path):
     assert c1["photons"] == c2["photons"] == 5  # one per light
     for k in ("casts", "bounces", "deposits", "kept"):
         assert c1[k] == c2[k], k
+
+
+def test_overflowing_store_keeps_as_many_records_on_two_ranks(tmp_path):
+    """The frame has ONE bounce store (reference src/Renderer.cpp:382-390, src/BounceStore.cpp:21-33: appends
+    beyond its capacity are dropped): sharded over two ranks every rank keeps its share of it, so the
+    frame holds as many records, and as much light, as the frame of one rank.  (With a whole store per
+    rank the two-rank frame would hold twice the records and come out twice as bright.)"""
+    scene, photons, capacity = "scenes/MultiCameraTest.json", 200_000, 20_000
+    one, c1 = render(1, scene, photons, True, str(tmp_path / "one"), capacity)
+    two, c2 = render(2, scene, photons, True, str(tmp_path / "two"), capacity)
+    assert c1["store_attempted"] == c2["store_attempted"] > 2 * capacity  # both overflow, by a wide margin
+    assert c1["store_size"] == capacity
+    assert capacity <= c2["store_size"] <= capacity + 2
+    lit = 0
+    for name in one.files:
+        a, b = one[name].astype(np.float64), two[name].astype(np.float64)
+        if a.sum() <= 0:
+            continue
+        lit += 1
+        # which records are kept differs (the first to arrive on each GPU), how many does not
+        assert abs(b.sum() / a.sum() - 1.0) < 0.15, (name, a.sum(), b.sum())
+    assert lit > 0

@@ -892,3 +892,39 @@ def test_errors_are_codes_not_crashes(rt, scene_opener, tracer_mod):
     assert e.value.code == 1
     with pytest.raises(tracer_mod.TracerError):
         rt.Tracer(scene, device=99)
+
+
+def test_store_limit_is_the_store_capacity_of_a_rank(rt, scene_opener):
+    """rt_set_store_limit: the store takes that many records in all and counts the rest as dropped, as the
+    reference's store does at its capacity (src/BounceStore.cpp:21-33); 0 gives the capacity back; a limit
+    below what the store holds is refused; the records kept under a limit are records of the full run."""
+    entry = {"scene": "tests/scenes/mixed.json", "photons_per_light": 3000}
+    scene, tracer, orc = _open(rt, scene_opener, entry)
+    setup = O.frame_setup(orc, O.RNG_COUNTER, O.MATH_PORTABLE)
+    keep = setup["keep_radius"]
+    tracer.set_probes(tracer.collect_probe_positions(), keep, keep, setup["store_capacity"])
+    tracer.reset()
+    tracer.trace(sink_mode=1)
+    full = tracer.counters()
+    everything = _sorted_records(tracer.store())
+    assert full["store_dropped"] == 0 and full["store_size"] > 40
+    limit = full["store_size"] // 3
+    with pytest.raises(RuntimeError):
+        tracer.set_store_limit(limit)  # the store holds more than that
+    tracer.reset()
+    tracer.set_store_limit(limit)
+    tracer.trace(sink_mode=1)
+    part = tracer.counters()
+    assert part["store_size"] == limit
+    assert part["store_attempted"] == full["store_attempted"]
+    assert part["store_dropped"] == full["store_attempted"] - limit
+    assert part["bounces"] == full["bounces"] and part["kept"] == full["kept"]
+    kept = tracer.store()
+    assert kept.shape[0] == limit
+    rows = {r.tobytes() for r in np.ascontiguousarray(everything)}
+    assert all(np.ascontiguousarray(r).tobytes() in rows for r in kept)
+    tracer.reset()
+    tracer.set_store_limit(0)
+    tracer.trace(sink_mode=1)
+    again = tracer.counters()
+    assert again["store_size"] == full["store_size"] and again["store_dropped"] == 0

@@ -87,3 +87,20 @@ def test_shard_ranges_tile_the_budget():
                 assert a + n == b
     with pytest.raises(ValueError):
         parallel.shard_range(10, 2, 2)
+
+
+def test_store_shares_add_up_to_the_one_store():
+    """A sharded frame has the reference's ONE store (src/Renderer.cpp:382-390): rank 0 keeps the emitter
+    deposits, and the ranks' equal shares of the rest add up to it (rounded up per rank; a share is at
+    least one record, since a limit of 0 means the whole store)."""
+    for capacity, emitters in ((7_548_416, 0), (40_000_000, 12_345_678), (1000, 999), (10, 25), (1, 0)):
+        for world in (1, 2, 3, 8):
+            shares = [parallel.store_share(capacity, emitters, r, world) for r in range(world)]
+            kept_emitters = min(emitters, capacity)
+            part = -(-(capacity - kept_emitters) // world)
+            assert shares == [max(1, (kept_emitters if r == 0 else 0) + part) for r in range(world)]
+            assert capacity <= sum(shares) <= capacity + 2 * world
+            if world == 1:
+                assert shares == [capacity]
+    with pytest.raises(ValueError):
+        parallel.store_share(10, 0, 2, 2)
