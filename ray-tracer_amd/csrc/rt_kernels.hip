@@ -16,8 +16,10 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 
 #include <hipcub/hipcub.hpp>
+#include <rocprim/rocprim.hpp>
 
 namespace rtd
 {
@@ -2639,9 +2641,23 @@ hipError_t sortStoreKeys(void* scratch, size_t* scratchBytes, const unsigned lon
                          unsigned long long* keysOut, const uint32_t* orderIn, uint32_t* orderOut, uint64_t n, int bits,
                          hipStream_t stream)
 {
-    // radix sort is stable: records of one cell keep their store order
+    // radix sort is stable: records of one cell keep their store order.  Up to a million pairs the library
+    // sorts by merging (a block sort and two launches for every doubling: two dozen launches for a store of a
+    // million records); the keys here are 20 to 40 bits wide, three to five radix passes, which are the
+    // faster way from a few ten thousand records on (RT_AMD_ONESWEEP_FROM=<records> moves the line).
+    using RadixFromSmall = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 4096>;
+    static const uint64_t radixFrom = [] {
+        const char* v = std::getenv("RT_AMD_ONESWEEP_FROM");
+        return v != nullptr ? std::strtoull(v, nullptr, 10) : 65536ull;
+    }();
+    const unsigned int endBit = static_cast<unsigned int>(std::max(1, std::min(64, bits)));
+    if (n >= radixFrom)
+    {
+        return rocprim::radix_sort_pairs<RadixFromSmall>(scratch, *scratchBytes, keysIn, keysOut, orderIn, orderOut,
+                                                         static_cast<unsigned int>(n), 0u, endBit, stream);
+    }
     return hipcub::DeviceRadixSort::SortPairs(scratch, *scratchBytes, keysIn, keysOut, orderIn, orderOut,
-                                              static_cast<int>(n), 0, std::max(1, std::min(64, bits)), stream);
+                                              static_cast<int>(n), 0, static_cast<int>(endBit), stream);
 }
 
 namespace
