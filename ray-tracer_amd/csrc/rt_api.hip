@@ -2669,7 +2669,7 @@ int32_t rt_gather(rt_tracer* tracer, int32_t camera, double gather_cell_size, do
         if (cache.total > 0)
         {
             // One lane per sampled pixel looks up the pixel's rows; a pixel with more records in them than a
-            // limit is handed to a wave of its own in a second launch.  Up to a few million gather points
+            // limit is handed to two waves of its own in a second launch.  Up to a few million gather points
             // the limit is one record — the first launch only sorts out the pixels with nothing to add, and
             // waves do the gathering, 64 records at a time —; a 4K frame has more pixels than that pays for,
             // and each of its pixels few records: there a lane keeps its pixel unless it looks at a crowded
@@ -2686,6 +2686,9 @@ int32_t rt_gather(rt_tracer* tracer, int32_t camera, double gather_cell_size, do
                 if (g.heavyPixels.count < static_cast<size_t>(cache.pixels)) g.heavyPixels.allocate(static_cast<size_t>(cache.pixels));
                 check(hipMemsetAsync(stats.ptr + 3, 0, sizeof(unsigned long long), tracer->stream), "hipMemsetAsync heavy count");
                 args.heavyThreshold = heavy;
+                // (RT_AMD_GATHER_WAVES=1|2|4|8: the waves that share a pixel of the second launch)
+                args.heavyWaves = 2;
+                if (const char* v = std::getenv("RT_AMD_GATHER_WAVES")) args.heavyWaves = static_cast<uint32_t>(std::max(1, std::atoi(v)));
                 args.heavyPixels = g.heavyPixels.ptr;
                 args.heavyCount = stats.ptr + 3;
             }
@@ -2695,7 +2698,7 @@ int32_t rt_gather(rt_tracer* tracer, int32_t camera, double gather_cell_size, do
             {
                 unsigned long long handedOver = 0;
                 check(hipMemcpy(&handedOver, stats.ptr + 3, sizeof(handedOver), hipMemcpyDeviceToHost), "hipMemcpy heavy count");
-                std::fprintf(stderr, "[rt_amd] gather: directory kind %d (%d x %d x %d), %llu of %lld pixels handed to a wave each\n",
+                std::fprintf(stderr, "[rt_amd] gather: directory kind %d (%d x %d x %d), %llu of %lld pixels handed over to waves of their own\n",
                              args.directoryKind, args.cellDim[0], args.cellDim[1], args.cellDim[2], handedOver,
                              static_cast<long long>(cache.pixels));
             }

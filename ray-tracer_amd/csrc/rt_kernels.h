@@ -213,9 +213,10 @@ struct GatherArgs
     const uint32_t* cellStart;
     int32_t cellMin[3], cellDim[3];
     // One lane per pixel, with the directory: a pixel one of whose gather points has more than
-    // heavyThreshold records in its rows of cells is left to a second launch, a wave per pixel, and
+    // heavyThreshold records in its rows of cells is left to a second launch, heavyWaves waves per pixel, and
     // appended to heavyPixels (heavyCount: how many so far).  0: every pixel is done where it is.
     uint32_t heavyThreshold;
+    uint32_t heavyWaves;  // waves that work together on a pixel of the second launch (1, 2, 4 or 8)
     uint32_t* heavyPixels;
     unsigned long long* heavyCount;
     // Second launch: the pixels to work on (null: all of them, thread by thread)

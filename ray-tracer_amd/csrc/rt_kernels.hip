@@ -1873,10 +1873,40 @@ RT_DEV uint32_t groupBits(unsigned long long waveMask, int groupBase)
     return G == 64 ? 0u : static_cast<uint32_t>((waveMask >> groupBase) & ((1ull << (G & 63)) - 1));
 }
 
-template <int G>
-RT_DEV Color gatherRadianceGroup(const GatherArgs& a, const GatherPoint& gp, int member, int groupBase,
-                                 unsigned long long* deposits)
+// Several waves on one pixel (gatherBlockKernel): what a wave's 64 records contribute waits here, in two
+// sets used in turn, for the block's first wave to add it in record order.
+template <int W>
+struct GatherStage
 {
+    unsigned long long mask[2][W];
+    float r[2][W][64], g[2][W][64], b[2][W][64];
+};
+
+// W > 1 (with G = 64): the block's W waves take the footprint's records 64 x W at a time, a wave 64 of them;
+// every wave runs the tests and the BRDF of its records, and the first wave then adds what passed, wave by
+// wave, in the order of the records.  The walk of a crowded pixel — thousands of records, each step a round
+// trip to memory — is then W steps wide, and the additions, the one part that has to be serial, are all that
+// stays so.  Every wave works out the rows' ranges for itself (they are the same numbers), so that the loops
+// around the barriers run the same number of times in all of them; the result is the first wave's.
+template <int G, int W = 1>
+RT_DEV Color gatherRadianceGroup(const GatherArgs& a, const GatherPoint& gp, int member, int groupBase,
+                                 unsigned long long* deposits, GatherStage<W>* stage = nullptr, int* stageTurn = nullptr)
+{
+    static_assert(W == 1 || G == 64, "several waves a pixel only with a whole wave a group");
+    const int wave = W > 1 ? static_cast<int>(threadIdx.x >> 6) : 0;
+    // which set of the stage this round writes: the sets alternate from round to round across gather points
+    // and pixels alike (the caller keeps the count), so that a round never writes the set the first wave may
+    // still be reading
+    int turn = W > 1 ? *stageTurn : 0;
+    struct KeepTurn
+    {
+        int* to;
+        const int* from;
+        RT_DEV ~KeepTurn()
+        {
+            if (to != nullptr) *to = *from;
+        }
+    } keepTurn{W > 1 ? stageTurn : nullptr, &turn};
     const Color black{0.0f, 0.0f, 0.0f};
     const bool isEmitter = gp.material < 0;
     const Vec wo = mk(gp.viewDir[0], gp.viewDir[1], gp.viewDir[2]);
@@ -2014,7 +2044,14 @@ RT_DEV Color gatherRadianceGroup(const GatherArgs& a, const GatherPoint& gp, int
             }
             // the group's verdicts, then the additions in record order
             const unsigned long long passMask = __ballot(passes);
-            if (G == 64)
+            if (G == 64 && W > 1)
+            {
+                if (member == 0) stage->mask[turn][wave] = passMask;
+                stage->r[turn][wave][member] = contribution.r;
+                stage->g[turn][wave][member] = contribution.g;
+                stage->b[turn][wave][member] = contribution.b;
+            }
+            else if (G == 64)
             {
                 const uint32_t passed = static_cast<uint32_t>(__builtin_popcountll(passMask));
                 kept += passed;
@@ -2068,9 +2105,40 @@ RT_DEV Color gatherRadianceGroup(const GatherArgs& a, const GatherPoint& gp, int
                 const uint32_t holderEnd = __shfl(myEnd, static_cast<int>(holder), 64);
                 return static_cast<uint64_t>(holderEnd - (holderUpTo - place));
             };
-            for (uint32_t base = 0; base < total; base += 64)
+            if (W > 1)
             {
-                settle(fetch(recordAt(base)), base + static_cast<uint32_t>(member) < total);
+                // (total is the same in every wave: the barrier is reached by all of them or none)
+                for (uint32_t round = 0; round < total; round += 64u * W)
+                {
+                    const uint32_t base = round + 64u * static_cast<uint32_t>(wave);
+                    settle(fetch(recordAt(base)), base + static_cast<uint32_t>(member) < total);
+                    __syncthreads();
+                    if (wave == 0)
+                    {
+#pragma unroll
+                        for (int w = 0; w < W; ++w)
+                        {
+                            const unsigned long long passMask = stage->mask[turn][w];
+                            const uint32_t passed = static_cast<uint32_t>(__builtin_popcountll(passMask));
+                            kept += passed;
+                            if (passed != 0)
+                            {
+                                const Color staged{stage->r[turn][w][member], stage->g[turn][w][member], stage->b[turn][w][member]};
+                                orderedAdd(passMask, passed, staged, &sum);
+                            }
+                        }
+                    }
+                    // the next round writes the other set: nobody writes this one again before the first wave,
+                    // done with it, has passed the next barrier
+                    turn ^= 1;
+                }
+            }
+            else
+            {
+                for (uint32_t base = 0; base < total; base += 64)
+                {
+                    settle(fetch(recordAt(base)), base + static_cast<uint32_t>(member) < total);
+                }
             }
         }
         else
@@ -2163,6 +2231,69 @@ __global__ __launch_bounds__(256) void gatherGroupKernel(const GatherArgs a)
     {
         if (totals[0] != 0) atomicAdd(a.stats + 0, totals[0]);
         if (totals[1] != 0) atomicAdd(a.stats + 1, totals[1]);
+    }
+}
+
+// The pixels of a list, W waves each (see gatherRadianceGroup): a block takes the list's pixels in turns.
+template <int W>
+__global__ __launch_bounds__(64 * W) void gatherBlockKernel(const GatherArgs a)
+{
+    __shared__ GatherStage<W> stage;
+    int stageTurn = 0;
+    const int member = static_cast<int>(threadIdx.x & 63);
+    const bool first = threadIdx.x < 64;  // the wave that holds the sums
+    unsigned long long added = 0, depositsAccum = 0;
+    const int64_t listed = static_cast<int64_t>(*a.pixelListCount);
+    for (int64_t turn = blockIdx.x; turn < listed; turn += gridDim.x)
+    {
+        const int64_t i = static_cast<int64_t>(a.pixelList[turn]);
+        if (!(i < a.pixels && a.counts[i] != 0))
+        {
+            continue;  // (the same for the whole block)
+        }
+        const Camera& cam = a.scene.cameras[a.camera];
+        const GatherPoint* points = a.points + a.offsets[i];
+        Color acc{0.0f, 0.0f, 0.0f};
+        unsigned long long addedHere = 0;
+        for (uint32_t k = 0; k < a.counts[i]; ++k)
+        {
+            const GatherPoint& gp = points[k];
+            if (gp.material >= a.scene.materialCount)
+            {
+                continue;
+            }
+            unsigned long long deposits = 0;
+            const Color radiance = gatherRadianceGroup<64, W>(a, gp, member, 0, &deposits, &stage, &stageTurn);
+            if (!first)
+            {
+                continue;  // (no barrier below this line)
+            }
+            const Color throughput{gp.throughput[0], gp.throughput[1], gp.throughput[2]};
+            const Color contribution = throughput * radiance * gp.sampleWeight;
+            depositsAccum += deposits;
+            if (contribution.r == 0.0f && contribution.g == 0.0f && contribution.b == 0.0f)
+            {
+                continue;
+            }
+            acc.r += contribution.r;
+            acc.g += contribution.g;
+            acc.b += contribution.b;
+            addedHere += 1;
+        }
+        added += addedHere;
+        const uint64_t w = static_cast<uint64_t>(cam.width), h = static_cast<uint64_t>(cam.height);
+        const uint64_t at = ((static_cast<uint64_t>(points[0].py) * w) + static_cast<uint64_t>(points[0].px)) * 3;
+        if (threadIdx.x == 0 && addedHere != 0 && at + 2 < w * h * 3)
+        {
+            atomicAdd(cam.buffer + at + 0, acc.r);
+            atomicAdd(cam.buffer + at + 1, acc.g);
+            atomicAdd(cam.buffer + at + 2, acc.b);
+        }
+    }
+    if (threadIdx.x == 0)
+    {
+        if (added != 0) atomicAdd(a.stats + 0, added);
+        if (depositsAccum != 0) atomicAdd(a.stats + 1, depositsAccum);
     }
 }
 
@@ -2711,8 +2842,25 @@ void launchGather(const GatherArgs& args, int lanesPerPixel, int computeUnits, h
             rest.heavyThreshold = 0;
             rest.pixelList = args.heavyPixels;
             rest.pixelListCount = args.heavyCount;
-            hipLaunchKernelGGL(gatherGroupKernel<64>, dim3(static_cast<uint32_t>(std::max(1, computeUnits) * 32)), dim3(64), 0, stream,
-                               rest);
+            // the pixels left over, two waves each (see gatherRadianceGroup): a grid that fills the chip takes them
+            // in turns
+            const uint32_t places = static_cast<uint32_t>(std::max(1, computeUnits) * 32);  // waves the grid holds
+            if (args.heavyWaves >= 8)
+            {
+                hipLaunchKernelGGL(gatherBlockKernel<8>, dim3(places / 8), dim3(512), 0, stream, rest);
+            }
+            else if (args.heavyWaves >= 4)
+            {
+                hipLaunchKernelGGL(gatherBlockKernel<4>, dim3(places / 4), dim3(256), 0, stream, rest);
+            }
+            else if (args.heavyWaves >= 2)
+            {
+                hipLaunchKernelGGL(gatherBlockKernel<2>, dim3(places / 2), dim3(128), 0, stream, rest);
+            }
+            else
+            {
+                hipLaunchKernelGGL(gatherGroupKernel<64>, dim3(places), dim3(64), 0, stream, rest);
+            }
         }
     }
 }

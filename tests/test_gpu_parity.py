@@ -517,11 +517,12 @@ GATHER_SCENES = {
 }
 
 
-@pytest.mark.parametrize("lanes,hand_over", [(0, None), (1, 0), (1, 3), (8, None), (64, None)])
+@pytest.mark.parametrize("lanes,hand_over", [(0, None), (1, 0), (1, 3), (8, None), (64, None), (-1, None), (-4, None), (-8, None)])
 @pytest.mark.parametrize("name", sorted(GATHER_SCENES))
 def test_gather_equals_oracle(rt, scene_opener, name, lanes, hand_over, monkeypatch):
     """(The gather gives a sampled pixel a lane and hands it to a wave when it meets more records than a
-    limit: (0, None) is its own choice, (1, 0) keeps every pixel in its lane, (1, 3) mixes both, 8 and 64 force
+    limit: (0, None) is its own choice — the pixels handed over go to two waves each; -1, -4 and -8 make that one,
+    four or eight waves —, (1, 0) keeps every pixel in its lane, (1, 3) mixes both, 8 and 64 force
     that many lanes per pixel in one launch; the result may not depend on it by a single bit.)
     The whole probe-mode frame after the photon pass.  (1) Given the SAME store, record for
     record in the same order, the device gather (sort by cell, one thread per pixel) returns
@@ -529,7 +530,10 @@ def test_gather_equals_oracle(rt, scene_opener, name, lanes, hand_over, monkeypa
     pre-loaded, photon pass, gather) holds the same store as a multiset and the same image up
     to the rounding of a different float summation order (the reference's own result depends
     on append order the same way when it runs more than one worker)."""
-    if lanes:
+    if lanes < 0:
+        # its own choice, but the pixels handed over are taken by 1, 4 or 8 waves each instead of by two
+        monkeypatch.setenv("RT_AMD_GATHER_WAVES", str(-lanes))
+    elif lanes:
         monkeypatch.setenv("RT_AMD_GATHER_LANES", str(lanes))
     if hand_over is not None:
         monkeypatch.setenv("RT_AMD_GATHER_HEAVY", str(hand_over))
