@@ -194,6 +194,12 @@ int32_t rt_synchronize(rt_tracer* tracer);
  * set up (rt_set_probes / rt_set_splat: those allocate) and reset (rt_reset: does not) before. */
 int32_t rt_trace_static(rt_tracer* tracer, const rt_trace_params* params);
 uint64_t rt_trace_static_max_photons(void);
+/* Device allocations (hipMalloc) and releases (hipFree) the library has made in this process so far;
+ * every one of them goes through one wrapper, which counts.  No counterpart in the reference: it is
+ * how a caller (and tests/test_zz_no_alloc.py) checks that a call allocated nothing. */
+void rt_debug_device_allocations(uint64_t* allocations, uint64_t* releases);
+/* hipMemGetInfo of GPU `device`: bytes free and in all (either may be NULL).  Also for that check. */
+int32_t rt_debug_device_memory(int32_t device, uint64_t* free_bytes, uint64_t* total_bytes);
 
 /* Device time of the last rt_trace, from HIP events recorded on the tracer's stream around
  * its two stages: the emission-order sort of the photon ids (a bucket sort by emission cell for a
@@ -219,9 +225,12 @@ int32_t rt_read_counters(rt_tracer* tracer, rt_counters* out);
  * src/Buffer.cpp:22-37) is merged here by an RCCL all-reduce.  rt_allreduce sums every camera buffer
  * of the tracer over the ranks of `rccl_comm` (an ncclComm_t passed as void*; the caller made it, with
  * ncclCommInitRank in a process per GPU or with rt_comm_init_all in one process), in place, on the
- * tracer's stream, and waits; `totals` (optional) receives the counters summed over the ranks
- * (deposited_power too; store_size is the sum of the ranks' stores).  Every rank calls it once per
- * frame, after its gather.  RCCL (librccl.so) is loaded when first needed: RT_ERR_STATE if it cannot be. */
+ * tracer's stream, and waits; `totals` receives the counters summed over the ranks (deposited_power
+ * too; store_size is the sum of the ranks' stores) and may be NULL on any rank: the counters are reduced
+ * either way, so the sequence of collectives is the same on every rank whatever each passes (cameras in
+ * index order, then the fifteen integer counters, then the three powers).  Every rank calls it once per
+ * frame, after its gather, with tracers of the same scene.  RCCL (librccl.so) is loaded when first
+ * needed: RT_ERR_STATE if it cannot be. */
 int32_t rt_allreduce(rt_tracer* tracer, void* rccl_comm, rt_counters* totals);
 /* One process, n GPUs: ncclCommInitAll over `devices`; comms[i] belongs to devices[i] and is to be used
  * from its own thread.  rt_comm_destroy releases one of them. */

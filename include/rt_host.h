@@ -49,6 +49,18 @@ int rth_material_evaluate(const rth_scene* scene, int32_t material, const double
  * rgb[height][width][3] as a 16-bit RGB PNG with a "Title" text chunk when title is not empty. */
 int rth_write_png16(const char* path, const uint16_t* rgb, int32_t width, int32_t height, const char* title);
 
+/* The control flow of a frame whose photons are spread over several GPUs of one process
+ * (Renderer::renderFrame under RT_AMD_DEVICES; host/RankFrames.h), run with stand-in shares and a
+ * stand-in collective, no GPU: `world` ranks each trace eight pieces of a share, rank `failing_rank`
+ * (-1: none) then throws, rank 0 gives the frame up after `cancel_after_pieces` of its pieces (-1: never);
+ * the ranks meet; the collective — which nobody leaves before all have entered — is entered only if no
+ * share failed.  Receives the ranks that entered the collective, the pieces traced over all ranks and the
+ * frame's failure text (empty: none).  Returns 0, or 2 when the collective was entered by some ranks
+ * only, i.e. a real one would have hung.  The reference rethrows a worker's exception after stopping the
+ * other workers (reference src/Renderer.cpp:511-523,584-595); this is how that is tested here. */
+int rth_test_rank_frames(int32_t world, int32_t failing_rank, int32_t cancel_after_pieces, int32_t* entered_collective,
+                         int32_t* pieces_traced, char* text, int32_t text_capacity);
+
 #ifdef __cplusplus
 }
 #endif

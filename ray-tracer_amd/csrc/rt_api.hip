@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <array>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -56,6 +57,10 @@ void require(bool ok, const char* what)
     }
 }
 
+// Device allocations and releases this library has made since it was loaded (every one goes through
+// DeviceArray): what rt_debug_device_allocations reports.
+std::atomic<uint64_t> g_deviceAllocations{0}, g_deviceReleases{0};
+
 template <typename T>
 struct DeviceArray
 {
@@ -70,6 +75,7 @@ struct DeviceArray
         if (ptr)
         {
             (void)hipFree(ptr);
+            g_deviceReleases.fetch_add(1, std::memory_order_relaxed);
             ptr = nullptr;
             count = 0;
         }
@@ -80,6 +86,7 @@ struct DeviceArray
         if (n > 0)
         {
             check(hipMalloc(reinterpret_cast<void**>(&ptr), n * sizeof(T)), "hipMalloc");
+            g_deviceAllocations.fetch_add(1, std::memory_order_relaxed);
             count = n;
         }
     }
@@ -221,6 +228,7 @@ struct rt_tracer
     // shared device scalars: [0] work counter, [1] store cursor
     DeviceArray<unsigned long long> scalars;
     DeviceArray<rtd::DeviceCounters> counters;
+    DeviceArray<unsigned char> countersStaged;  // an rt_counters on the device, for rt_allreduce
     // emission-order list of a pass's photon ids
     DeviceArray<uint32_t> sortIds, sortOrder, sortKeysIn, sortKeysOut;
     const uint32_t* orderList = nullptr;          // the finished emission order: sortOrder or (large passes) sortIds
@@ -1365,6 +1373,7 @@ int32_t rt_create(const rt_scene* scene, int32_t device, rt_tracer** out)
         check(hipGetDeviceProperties(&prop, device), "hipGetDeviceProperties");
         t->computeUnits = prop.multiProcessorCount;
         t->staticScratch = staticScratchOf(device);
+        t->countersStaged.allocate(sizeof(rt_counters));
         check(rtd::sortEmissionPairs(nullptr, &t->staticSortBytes, nullptr, nullptr, nullptr, nullptr, kStaticMaxIds,
                                      static_cast<int>(std::max<int64_t>(1, t->lightCount)), 0, nullptr),
               "sort size query");
@@ -1419,7 +1428,6 @@ void setProbes(rt_tracer* tracer, const double* probes, bool probesOnDevice, uin
     if (buildProbesOnDevice(tracer, probes, probesOnDevice, n, invCellSize, keepRadius))
     {
         tracer->probesSet = true;
-    tracer->probeVersion += 1;
         tracer->probeVersion += 1;
         return;
     }
@@ -2101,6 +2109,23 @@ int32_t rt_trace(rt_tracer* tracer, const rt_trace_params* params)
 
 uint64_t rt_trace_static_max_photons(void) { return kStaticMaxIds; }
 
+void rt_debug_device_allocations(uint64_t* allocations, uint64_t* releases)
+{
+    if (allocations != nullptr) *allocations = g_deviceAllocations.load(std::memory_order_relaxed);
+    if (releases != nullptr) *releases = g_deviceReleases.load(std::memory_order_relaxed);
+}
+
+int32_t rt_debug_device_memory(int32_t device, uint64_t* free_bytes, uint64_t* total_bytes)
+{
+    return guarded([&]() {
+        check(hipSetDevice(device), "hipSetDevice");
+        size_t freeNow = 0, total = 0;
+        check(hipMemGetInfo(&freeNow, &total), "hipMemGetInfo");
+        if (free_bytes != nullptr) *free_bytes = freeNow;
+        if (total_bytes != nullptr) *total_bytes = total;
+    });
+}
+
 int32_t rt_trace_static(rt_tracer* tracer, const rt_trace_params* params)
 {
     return guarded([&]() {
@@ -2118,9 +2143,20 @@ int32_t rt_trace_static(rt_tracer* tracer, const rt_trace_params* params)
                                                 " photons (photon_count x lights) exceed the static scratch's " +
                                                 std::to_string(kStaticMaxIds) + "; split the range or use rt_trace");
         }
-        if (tracer->staticSortBytes > kStaticSortBytes)
+        // The sort picks its algorithm (and with it its work space) by the number of pairs and does not check
+        // the size it is handed: ask what THIS pass needs (a host-side query, nothing is launched) as well as
+        // what the largest one would.
+        size_t needed = 0;
+        if (args.totalWork > 0)
         {
-            throw ApiError(RT_ERR_STATE, "rt_trace_static: the radix sort asks for " + std::to_string(tracer->staticSortBytes) +
+            check(rtd::sortEmissionPairs(nullptr, &needed, nullptr, nullptr, nullptr, nullptr, args.totalWork,
+                                         static_cast<int>(std::max<int64_t>(1, tracer->lightCount)), 0, nullptr),
+                  "sort size query");
+        }
+        needed = std::max(needed, tracer->staticSortBytes);
+        if (needed > kStaticSortBytes)
+        {
+            throw ApiError(RT_ERR_STATE, "rt_trace_static: the radix sort asks for " + std::to_string(needed) +
                                              " bytes of work space, the static scratch reserves " +
                                              std::to_string(kStaticSortBytes));
         }
@@ -2293,25 +2329,25 @@ int32_t rt_allreduce(rt_tracer* tracer, void* rccl_comm, rt_counters* totals)
             checkRccl(lib.allReduce(camera.buffer, camera.buffer, floats, Rccl::kFloat32, Rccl::kSum, rccl_comm, tracer->stream),
                       "ncclAllReduce camera buffer");
         }
-        if (totals != nullptr)
-        {
-            // the counters as rt_read_counters reports them, summed: fifteen integers and three doubles
-            rt_counters mine{};
-            const int32_t code = rt_read_counters(tracer, &mine);
-            if (code != RT_OK) throw ApiError(code, rt_last_error());
-            constexpr size_t kIntegers = offsetof(rt_counters, deposited_power) / sizeof(uint64_t);
-            static_assert(sizeof(rt_counters) == kIntegers * sizeof(uint64_t) + 3 * sizeof(double), "rt_counters layout");
-            DeviceArray<unsigned char> staged;
-            staged.allocate(sizeof(rt_counters));
-            check(hipMemcpyAsync(staged.ptr, &mine, sizeof(mine), hipMemcpyHostToDevice, tracer->stream), "hipMemcpyAsync counters");
-            checkRccl(lib.allReduce(staged.ptr, staged.ptr, kIntegers, Rccl::kUint64, Rccl::kSum, rccl_comm, tracer->stream),
-                      "ncclAllReduce counters");
-            unsigned char* powers = staged.ptr + kIntegers * sizeof(uint64_t);
-            checkRccl(lib.allReduce(powers, powers, 3, Rccl::kFloat64, Rccl::kSum, rccl_comm, tracer->stream),
-                      "ncclAllReduce deposited power");
-            check(hipMemcpyAsync(totals, staged.ptr, sizeof(*totals), hipMemcpyDeviceToHost, tracer->stream), "hipMemcpyAsync totals");
-        }
+        // The counters as rt_read_counters reports them, summed: fifteen integers and three doubles.  They
+        // are reduced whether or not the caller wants them: the ranks of a communicator must issue the same
+        // collectives in the same order, whatever each of them passed for `totals`.
+        rt_counters mine{};
+        const int32_t code = rt_read_counters(tracer, &mine);
+        if (code != RT_OK) throw ApiError(code, rt_last_error());
+        constexpr size_t kIntegers = offsetof(rt_counters, deposited_power) / sizeof(uint64_t);
+        static_assert(sizeof(rt_counters) == kIntegers * sizeof(uint64_t) + 3 * sizeof(double), "rt_counters layout");
+        unsigned char* staged = tracer->countersStaged.ptr;
+        check(hipMemcpyAsync(staged, &mine, sizeof(mine), hipMemcpyHostToDevice, tracer->stream), "hipMemcpyAsync counters");
+        checkRccl(lib.allReduce(staged, staged, kIntegers, Rccl::kUint64, Rccl::kSum, rccl_comm, tracer->stream),
+                  "ncclAllReduce counters");
+        unsigned char* powers = staged + kIntegers * sizeof(uint64_t);
+        checkRccl(lib.allReduce(powers, powers, 3, Rccl::kFloat64, Rccl::kSum, rccl_comm, tracer->stream),
+                  "ncclAllReduce deposited power");
+        rt_counters summed{};
+        check(hipMemcpyAsync(&summed, staged, sizeof(summed), hipMemcpyDeviceToHost, tracer->stream), "hipMemcpyAsync totals");
         check(hipStreamSynchronize(tracer->stream), "hipStreamSynchronize");
+        if (totals != nullptr) *totals = summed;
     });
 }
 

@@ -2,6 +2,7 @@
 
 #include "Flatten.h"
 #include "FrameSetup.h"
+#include "RankFrames.h"
 #include "rt_amd.h"
 
 #include <algorithm>
@@ -35,6 +36,9 @@ void check(int32_t code)
 struct TracerHandle
 {
     rt_tracer* ptr = nullptr;
+    TracerHandle() = default;
+    TracerHandle(const TracerHandle&) = delete;
+    TracerHandle& operator=(const TracerHandle&) = delete;
     ~TracerHandle()
     {
         if (ptr) rt_destroy(ptr);
@@ -80,74 +84,81 @@ void shardOf(size_t perLight, int rank, int world, size_t* first, size_t* count)
     *count = perLight * (static_cast<size_t>(rank) + 1) / static_cast<size_t>(world) - *first;
 }
 
-// What every rank but the first does for a frame, on its own GPU and thread: the same probe pass and
-// probe index (they are replicated), its share of the photons into its own store, its own gather into its
-// own camera buffers, then the all-reduce, which the first rank joins from renderFrame.  Emitter deposits
-// are the first rank's alone (a gather is linear in the records, so the sum of the ranks' images is the
-// image of the union of their stores).  Returns an error text, empty when all went well.
-std::string otherRankFrame(const rt_scene* scene, const FrameDerived& derived, int device, int rank, int world, void* comm,
-                           const std::vector<bool>& gathers)
+// RT_AMD_FAIL_RANK=<rank>: that rank's share of the frame fails once it is done (a test switch for the
+// path a failing GPU takes: the frame must end with the rank's message, not hang).
+void failIfAskedTo(int rank)
 {
-    try
+    if (const char* v = std::getenv("RT_AMD_FAIL_RANK"))
     {
-        TracerHandle tracer;
-        check(rt_create(scene, device, &tracer.ptr));
-        const bool probeGather = scene->settings.use_probe_gather != 0;
-        if (probeGather)
+        if (std::atoi(v) == rank)
         {
-            for (size_t c = 0; c < gathers.size(); ++c)
-            {
-                if (!gathers[c]) continue;
-                uint64_t count = 0;
-                check(rt_collect_gather_points(tracer.ptr, static_cast<int32_t>(c), nullptr, 0, &count, nullptr));
-            }
-            uint64_t probeCount = 0, capacity = 0;
-            check(rt_set_probes_from_cameras(tracer.ptr, derived.keepRadius, derived.keepRadius, 256,
-                                             scene->settings.bounce_store_capacity, &probeCount, &capacity));
-            // the emitter deposits are laid down once to learn their number (rank 0 keeps its own), then
-            // the store is held to this rank's share
-            check(rt_reset(tracer.ptr));
-            const double emitterGatherCell = derived.sceneDepthFootprint > 0.0 ? derived.sceneDepthFootprint : derived.cellSize;
-            uint64_t emitterKept = 0;
-            check(rt_deposit_emitters(tracer.ptr, std::max(emitterGatherCell * 0.5, 1e-6), nullptr, &emitterKept));
-            check(rt_reset(tracer.ptr));
-            check(rt_set_store_limit(tracer.ptr, storeShareOf(capacity, emitterKept, rank, world)));
+            throw std::runtime_error("injected failure of rank " + std::to_string(rank) + " (RT_AMD_FAIL_RANK)");
         }
-        else
+    }
+}
+
+// What every rank but the first does for a frame before the ranks meet, on its own GPU and thread: the
+// same probe pass and probe index (they are replicated), its share of the photons into its own store — in
+// `pieces` index ranges, none started once the frame is being given up —, its own gather into its own camera
+// buffers.  Emitter deposits are the first rank's alone (a gather is linear in the records, so the sum of
+// the ranks' images is the image of the union of their stores).  Throws what went wrong.
+void otherRankShare(TracerHandle& tracer, const rt_scene* scene, const FrameDerived& derived, int device, int rank, int world,
+                    const std::vector<bool>& gathers, size_t pieces, const RankFrames& frames)
+{
+    check(rt_create(scene, device, &tracer.ptr));
+    const bool probeGather = scene->settings.use_probe_gather != 0;
+    if (probeGather)
+    {
+        for (size_t c = 0; c < gathers.size(); ++c)
         {
-            const uint64_t depositBound = static_cast<uint64_t>(scene->settings.photons_per_light) *
-                                          static_cast<uint64_t>(std::max<int64_t>(1, scene->light_count)) *
-                                          (static_cast<uint64_t>(std::max(0, scene->settings.bounce_threshold)) + 1);
-            check(rt_set_splat(tracer.ptr, derived.minSplatRadius, derived.cellSize,
-                               std::min<uint64_t>(1ull << 27, std::max<uint64_t>(1ull << 22, depositBound))));
+            if (!gathers[c]) continue;
+            uint64_t count = 0;
+            check(rt_collect_gather_points(tracer.ptr, static_cast<int32_t>(c), nullptr, 0, &count, nullptr));
         }
+        uint64_t probeCount = 0, capacity = 0;
+        check(rt_set_probes_from_cameras(tracer.ptr, derived.keepRadius, derived.keepRadius, 256,
+                                         scene->settings.bounce_store_capacity, &probeCount, &capacity));
+        // the emitter deposits are laid down once to learn their number (rank 0 keeps its own), then
+        // the store is held to this rank's share
         check(rt_reset(tracer.ptr));
-        size_t first = 0, count = 0;
-        shardOf(static_cast<size_t>(scene->settings.photons_per_light), rank, world, &first, &count);
-        if (count > 0)
-        {
-            rt_trace_params params{};
-            params.sink_mode = probeGather ? RT_SINK_PROBE : RT_SINK_SPLAT;
-            params.first_photon = first;
-            params.photon_count = count;
-            check(rt_trace(tracer.ptr, &params));
-        }
-        if (probeGather)
-        {
-            const double gatherCell = derived.sceneDepthFootprint > 0.0 ? derived.sceneDepthFootprint : derived.cellSize;
-            for (size_t c = 0; c < gathers.size(); ++c)
-            {
-                if (!gathers[c]) continue;
-                check(rt_gather(tracer.ptr, static_cast<int32_t>(c), gatherCell, derived.minSplatRadius, nullptr));
-            }
-        }
-        check(rt_allreduce(tracer.ptr, comm, nullptr));
-        return std::string();
+        const double emitterGatherCell = derived.sceneDepthFootprint > 0.0 ? derived.sceneDepthFootprint : derived.cellSize;
+        uint64_t emitterKept = 0;
+        check(rt_deposit_emitters(tracer.ptr, std::max(emitterGatherCell * 0.5, 1e-6), nullptr, &emitterKept));
+        check(rt_reset(tracer.ptr));
+        check(rt_set_store_limit(tracer.ptr, storeShareOf(capacity, emitterKept, rank, world)));
     }
-    catch (const std::exception& failure)
+    else
     {
-        return failure.what();
+        const uint64_t depositBound = static_cast<uint64_t>(scene->settings.photons_per_light) *
+                                      static_cast<uint64_t>(std::max<int64_t>(1, scene->light_count)) *
+                                      (static_cast<uint64_t>(std::max(0, scene->settings.bounce_threshold)) + 1);
+        check(rt_set_splat(tracer.ptr, derived.minSplatRadius, derived.cellSize,
+                           std::min<uint64_t>(1ull << 27, std::max<uint64_t>(1ull << 22, depositBound))));
     }
+    check(rt_reset(tracer.ptr));
+    size_t first = 0, count = 0;
+    shardOf(static_cast<size_t>(scene->settings.photons_per_light), rank, world, &first, &count);
+    pieces = std::max<size_t>(1, pieces);
+    for (size_t piece = 0; piece < pieces && count > 0 && !frames.abandoned(); ++piece)
+    {
+        rt_trace_params params{};
+        params.sink_mode = probeGather ? RT_SINK_PROBE : RT_SINK_SPLAT;
+        params.first_photon = first + count * piece / pieces;
+        params.photon_count = first + count * (piece + 1) / pieces - params.first_photon;
+        if (params.photon_count == 0) continue;
+        check(rt_trace(tracer.ptr, &params));
+        check(rt_synchronize(tracer.ptr));
+    }
+    if (probeGather)
+    {
+        const double gatherCell = derived.sceneDepthFootprint > 0.0 ? derived.sceneDepthFootprint : derived.cellSize;
+        for (size_t c = 0; c < gathers.size(); ++c)
+        {
+            if (!gathers[c]) continue;
+            check(rt_gather(tracer.ptr, static_cast<int32_t>(c), gatherCell, derived.minSplatRadius, nullptr));
+        }
+    }
+    failIfAskedTo(rank);
 }
 
 }  // namespace
@@ -243,15 +254,16 @@ RenderResult renderFrame(const LoadedScene& scene, ProgressCallback progress, Pr
     }
 
     // More than one GPU: this thread is rank 0 on the configured device, every other rank gets a
-    // thread and a GPU of its own (devices 0 .. n-1 but the configured one last-swapped in), and the
-    // frames meet in the all-reduce after the gather.
+    // thread and a GPU of its own (devices 0 .. n-1 but the configured one last-swapped in).  Each rank
+    // does its share, the ranks meet, and only if every share came through do they enter the all-reduce
+    // (RankFrames.h): a rank that fails ends the frame with its message instead of hanging the others.
     const int world = shardWorld();
     const bool collective = world > 1 || (std::getenv("RT_AMD_COLLECTIVE") != nullptr && std::atoi(std::getenv("RT_AMD_COLLECTIVE")) != 0);
     Communicators communicators;
-    std::vector<std::future<std::string>> otherRanks;
+    std::vector<int32_t> devices(static_cast<size_t>(world), g_device);
+    std::vector<bool> gathers(cameras.size(), false);
     if (collective)
     {
-        std::vector<int32_t> devices(static_cast<size_t>(world));
         for (int r = 0; r < world; ++r)
         {
             devices[static_cast<size_t>(r)] = r;
@@ -260,25 +272,37 @@ RenderResult renderFrame(const LoadedScene& scene, ProgressCallback progress, Pr
         else devices[0] = g_device;
         communicators.comms.assign(static_cast<size_t>(world), nullptr);
         check(rt_comm_init_all(world, devices.data(), communicators.comms.data()));
-        std::vector<bool> gathers(cameras.size(), false);
         for (size_t c = 0; c < cameras.size(); ++c)
         {
             gathers[c] = cameras[c] && !debugCamera[c];
         }
-        for (int r = 1; r < world; ++r)
-        {
-            otherRanks.push_back(std::async(std::launch::async, otherRankFrame, &flat.scene, std::cref(derived),
-                                            devices[static_cast<size_t>(r)], r, world, communicators.comms[static_cast<size_t>(r)],
-                                            gathers));
-        }
         if (verbose) std::fprintf(stderr, "[rt_amd] %d GPU(s), frames summed by RCCL\n", world);
     }
-    TracerHandle tracer;
+    RankFrames frames(world);
+    std::vector<TracerHandle> rankTracers(static_cast<size_t>(world));
+    TracerHandle& tracer = rankTracers[0];
+
+    // Without a progress callback a rank's photons are one pass.  With one, they go out in up to eight
+    // index ranges (the sinks add up over ranges) and the callback is asked between them, so that
+    // returning false stops the frame early as it does in the reference's poll loop — on every rank; a
+    // range that has been launched runs to its end.
+    size_t shardFirst = 0, perLight = 0;  // this rank's share of the photons of every light
+    shardOf(settings.photonsPerLight, 0, world, &shardFirst, &perLight);
+    const size_t pieces = progress ? std::max<size_t>(1, std::min<size_t>(8, perLight / 1000000)) : 1;
+
+    // what the first rank's share leaves for the rest of the frame
+    double probeGatherMinRadius = 0.0;
+    std::vector<ProbeGatherResult> probeStats(cameras.size());
+    rt_counters counters{};
+    const double gatherCell = derived.sceneDepthFootprint > 0.0 ? derived.sceneDepthFootprint : derived.cellSize;
+    std::vector<std::array<uint64_t, 4>> gatherStats(cameras.size(), std::array<uint64_t, 4>{0, 0, 0, 0});
+    std::vector<double> gatherSeconds(cameras.size(), 0.0);
+    std::vector<bool> gathered(cameras.size(), false);
+
+    auto firstRankShare = [&]() {
     check(rt_create(&flat.scene, g_device, &tracer.ptr));
     stage("rt_create");
 
-    double probeGatherMinRadius = 0.0;
-    std::vector<ProbeGatherResult> probeStats(cameras.size());
     if (settings.useProbeGather)
     {
         // probe pass of every non-debug camera; the union of the record positions is the
@@ -331,17 +355,10 @@ RenderResult renderFrame(const LoadedScene& scene, ProgressCallback progress, Pr
     }
 
     // ---- the photon pass (replaces the Worker threads, reference src/Renderer.cpp:421-582) ----
-    // Without a progress callback the whole budget is one pass.  With one, the budget goes out in up
-    // to eight index ranges (the sinks add up over ranges) and the callback is asked between them, so
-    // that returning false stops the frame early as it does in the reference's poll loop — a range
-    // that has been launched runs to its end.
-    size_t shardFirst = 0, perLight = 0;  // this rank's share of the photons of every light
-    shardOf(settings.photonsPerLight, 0, world, &shardFirst, &perLight);
     const size_t totalWork = perLight * static_cast<size_t>(flat.scene.light_count);
-    const size_t pieces = progress ? std::max<size_t>(1, std::min<size_t>(8, perLight / 1000000)) : 1;
     size_t traced = 0;
     bool goOn = true;
-    for (size_t piece = 0; piece < pieces && goOn && perLight > 0; ++piece)
+    for (size_t piece = 0; piece < pieces && goOn && perLight > 0 && !frames.abandoned(); ++piece)
     {
         rt_trace_params params{};
         params.sink_mode = settings.useProbeGather ? RT_SINK_PROBE : RT_SINK_SPLAT;
@@ -376,22 +393,21 @@ RenderResult renderFrame(const LoadedScene& scene, ProgressCallback progress, Pr
         {
             goOn = progress(totalWork - traced);
         }
+        if (!goOn)
+        {
+            frames.cancel();  // the other ranks start no further range either
+        }
     }
     if (progress)
     {
         progress(0);
     }
-    rt_counters counters{};
     check(rt_read_counters(tracer.ptr, &counters));
     stage("photon pass (sort + trace)");
     result.photonPassSeconds =
         std::chrono::duration<double>(std::chrono::steady_clock::now() - photonPassStart).count();
     // Several GPUs: every rank gathers its own store into its own buffers first, then the buffers and
-    // the counters are summed over the ranks; from here on this rank holds the whole frame.
-    const double gatherCell = derived.sceneDepthFootprint > 0.0 ? derived.sceneDepthFootprint : derived.cellSize;
-    std::vector<std::array<uint64_t, 4>> gatherStats(cameras.size(), std::array<uint64_t, 4>{0, 0, 0, 0});
-    std::vector<double> gatherSeconds(cameras.size(), 0.0);
-    std::vector<bool> gathered(cameras.size(), false);
+    // the counters are summed over the ranks; from there on this rank holds the whole frame.
     if (collective)
     {
         for (size_t c = 0; c < cameras.size(); ++c)
@@ -405,16 +421,31 @@ RenderResult renderFrame(const LoadedScene& scene, ProgressCallback progress, Pr
             }
         }
         stage("gather");
-        check(rt_allreduce(tracer.ptr, communicators.comms[0], &counters));
-        for (std::future<std::string>& other : otherRanks)
+        failIfAskedTo(0);
+    }
+    };
+
+    if (collective)
+    {
+        const std::string failure = frames.run(
+            [&](int rank) {
+                if (rank == 0) firstRankShare();
+                else otherRankShare(rankTracers[static_cast<size_t>(rank)], &flat.scene, derived, devices[static_cast<size_t>(rank)], rank,
+                                    world, gathers, pieces, frames);
+            },
+            [&](int rank) {
+                check(rt_allreduce(rankTracers[static_cast<size_t>(rank)].ptr, communicators.comms[static_cast<size_t>(rank)],
+                                   rank == 0 ? &counters : nullptr));
+            });
+        if (!failure.empty())
         {
-            const std::string failure = other.get();
-            if (!failure.empty())
-            {
-                throw std::runtime_error("another GPU's share of the frame failed: " + failure);
-            }
+            throw std::runtime_error(failure);
         }
         stage("all-reduce");
+    }
+    else
+    {
+        firstRankShare();
     }
     if (counters.density_dropped > 0)
     {

@@ -5,10 +5,16 @@
 #include "Flatten.h"
 #include "FrameSetup.h"
 #include "PngWriter.h"
+#include "RankFrames.h"
 #include "SceneLoader.h"
 #include "rt_scene_io.h"
 
+#include <atomic>
+#include <chrono>
+#include <cstring>
+#include <stdexcept>
 #include <string>
+#include <thread>
 
 struct rth_scene
 {
@@ -145,6 +151,58 @@ int rth_write_png16(const char* path, const uint16_t* rgb, int32_t width, int32_
         return 1;
     }
     return 0;
+}
+
+int rth_test_rank_frames(int32_t world, int32_t failing_rank, int32_t cancel_after_pieces, int32_t* entered_collective,
+                         int32_t* pieces_traced, char* text, int32_t text_capacity)
+{
+    if (world < 1 || world > 64 || entered_collective == nullptr || pieces_traced == nullptr || text == nullptr || text_capacity < 1)
+    {
+        g_error = "rth_test_rank_frames: bad arguments";
+        return 1;
+    }
+    constexpr int kPieces = 8;
+    RankFrames frames(world);
+    std::atomic<int> entered{0}, traced{0};
+    bool stuck = false;
+    const std::string failure = frames.run(
+        [&](int rank) {
+            // a share: eight pieces of photons, none started once the frame is being given up
+            for (int piece = 0; piece < kPieces && !frames.abandoned(); ++piece)
+            {
+                std::this_thread::sleep_for(std::chrono::milliseconds(5));
+                traced.fetch_add(1);
+                if (rank == 0 && cancel_after_pieces >= 0 && piece + 1 >= cancel_after_pieces)
+                {
+                    frames.cancel();
+                }
+            }
+            if (rank == failing_rank)
+            {
+                throw std::runtime_error("injected failure of rank " + std::to_string(rank));
+            }
+        },
+        [&](int) {
+            // a collective: nobody leaves before everybody has entered (given up after two seconds, and
+            // reported, so that a broken meeting fails the test instead of hanging it)
+            entered.fetch_add(1);
+            const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(2);
+            while (entered.load() < world)
+            {
+                if (std::chrono::steady_clock::now() > deadline)
+                {
+                    stuck = true;
+                    throw std::runtime_error("collective entered by " + std::to_string(entered.load()) + " of " +
+                                             std::to_string(world) + " ranks: it would hang");
+                }
+                std::this_thread::sleep_for(std::chrono::milliseconds(1));
+            }
+        });
+    *entered_collective = entered.load();
+    *pieces_traced = traced.load();
+    std::strncpy(text, failure.c_str(), static_cast<size_t>(text_capacity) - 1);
+    text[text_capacity - 1] = '\0';
+    return stuck ? 2 : 0;
 }
 
 }  // extern "C"

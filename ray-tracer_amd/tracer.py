@@ -53,6 +53,8 @@ _SIGNATURES = {
     "rt_trace": (C.c_int32, [C.c_void_p, C.POINTER(RtTraceParams)]),
     "rt_trace_static": (C.c_int32, [C.c_void_p, C.POINTER(RtTraceParams)]),
     "rt_trace_static_max_photons": (C.c_uint64, []),
+    "rt_debug_device_allocations": (None, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "rt_debug_device_memory": (C.c_int32, [C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "rt_synchronize": (C.c_int32, [C.c_void_p]),
     "rt_allreduce": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "rt_comm_init_all": (C.c_int32, [C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_void_p)]),
@@ -137,6 +139,20 @@ def comm_init_all(devices):
 
 def comm_destroy(comm):
     _check(tracer_lib().rt_comm_destroy(comm))
+
+
+def device_allocations():
+    """(hipMalloc calls, hipFree calls) the library has made in this process so far."""
+    made, freed = C.c_uint64(), C.c_uint64()
+    tracer_lib().rt_debug_device_allocations(C.byref(made), C.byref(freed))
+    return int(made.value), int(freed.value)
+
+
+def device_memory(device=0):
+    """(free, total) bytes of a GPU, from hipMemGetInfo."""
+    free, total = C.c_uint64(), C.c_uint64()
+    _check(tracer_lib().rt_debug_device_memory(device, C.byref(free), C.byref(total)))
+    return int(free.value), int(total.value)
 
 
 def rows(fn_name, inputs, out_cols, out_dtype=np.float64, device=0):
@@ -249,11 +265,14 @@ class Tracer:
         out["deposited_power"] = np.array(list(c.deposited_power))
         return out
 
-    def allreduce(self, comm):
+    def allreduce(self, comm, want_totals=True):
         """Sum the camera buffers over the ranks of an RCCL communicator (see comm_init_all); returns
-        the counters summed over the ranks."""
+        the counters summed over the ranks (None when want_totals is False: the call then passes NULL,
+        which changes nothing about what is reduced)."""
         c = RtCounters()
-        _check(tracer_lib().rt_allreduce(self._handle, comm, C.byref(c)))
+        _check(tracer_lib().rt_allreduce(self._handle, comm, C.byref(c) if want_totals else None))
+        if not want_totals:
+            return None
         out = {name: int(getattr(c, name)) for name in COUNTER_FIELDS}
         out["deposited_power"] = np.array(list(c.deposited_power))
         return out

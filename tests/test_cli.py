@@ -149,6 +149,22 @@ def test_cli_frame_through_the_collective_path(tmp_path, probe_gather):
 
 
 @pytest.mark.gpu
+def test_cli_exits_1_when_a_rank_of_the_collective_path_fails(tmp_path):
+    """A rank that fails before the all-reduce ends the frame: exit 1 with the rank's message, as the
+    reference's main does with a worker's exception (reference src/Renderer.cpp:511-523,584-595,
+    src/main.cpp:141-149), not a wait inside the collective."""
+    scene = json.load(open(os.path.join(REPO, "tests", "scenes", "mixed.json")))
+    scene["$renderConfiguration"].update({"$photonsPerLight": 2000, "$renderName": "mixed",
+                                          "$renderPath": str(tmp_path / "out")})
+    path = tmp_path / "scene.json"
+    path.write_text(json.dumps(scene))
+    r = run_cli(str(path), env=dict(os.environ, RT_AMD_COLLECTIVE="1", RT_AMD_FAIL_RANK="0"))
+    assert r.returncode == 1
+    assert "injected failure of rank 0" in r.stdout + r.stderr
+    assert not os.path.exists(tmp_path / "out" / "mixed.0.png")
+
+
+@pytest.mark.gpu
 def test_cli_renders_keyframed_frames(rt, tmp_path):
     """$animation end to end: two frames of the keyframed scene (frame / frameRate is the frame
     time, reference src/main.cpp:95-100), each equal to the oracle's frame at that time, and

@@ -3,7 +3,9 @@
 Two calls in a row on one tracer, the second with a smaller input: the static scratch keeps
 the first call's contents, so the second one proves that what must start at zero is cleared.
 Bar: counters exact, the bounce store equal as a multiset bit for bit, splat buffers to 1e-5 of
-the peak (float atomics in a different order).
+the peak (float atomics in a different order).  That the call allocates nothing is checked twice
+over: the library counts its own hipMalloc / hipFree calls, and the GPU's free memory
+(hipMemGetInfo) is read before and after.
 """
 import numpy as np
 import pytest
@@ -86,3 +88,28 @@ def test_static_trace_refuses_what_it_cannot_hold(rt, scene_opener):
     assert tracer.counters()["photons"] == limit
     with pytest.raises(tracer_mod.TracerError):
         tracer.timings()  # no stage events on this path
+
+
+def test_static_trace_allocates_nothing(rt, scene_opener):
+    """Around rt_trace_static — the very first pass of a fresh tracer, then a smaller one — the library's
+    count of device allocations and releases stands still and so does the GPU's free memory."""
+    tracer_mod = rt.tracer
+    scene = scene_opener({"scene": "tests/scenes/mixed.json", "photons_per_light": 50_000})
+    tracer, orc = rt.Tracer(scene), O.Oracle(scene)
+    _probe_setup(tracer, orc)  # sink set-up allocates; it comes before
+    tracer.reset()
+    tracer.synchronize()
+    for count in (50_000, 6_000):
+        allocations_before = tracer_mod.device_allocations()
+        free_before = tracer_mod.device_memory(0)[0]
+        tracer.trace_static(sink_mode=1, photon_count=count)
+        tracer.synchronize()
+        assert tracer_mod.device_allocations() == allocations_before, f"pass of {count}"
+        assert tracer_mod.device_memory(0)[0] == free_before, f"pass of {count}"
+        counters = tracer.counters()  # reading back must not allocate either
+        assert tracer_mod.device_allocations() == allocations_before
+    assert counters["photons"] == (50_000 + 6_000) * scene.desc.light_count
+    # the counter does count: a pass through rt_trace has to allocate its emission-order lists
+    tracer.reset()
+    tracer.trace(sink_mode=1, photon_count=6_000)
+    assert tracer_mod.device_allocations()[0] > allocations_before[0]
