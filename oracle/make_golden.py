@@ -15,6 +15,8 @@ Fixtures written
                   splat buffers) for tests/scenes/{furnace,mixed}.json
     render_furnace.npz   Renderer::renderFrame on the furnace: store ledger, counters
     probes_*.npz  ProbeGather::collectGatherPoints per camera (19-column records + counters)
+    render_bombardment_overflow.npz   Renderer::renderFrame of the headline scene with a store that
+                  overflows 4.3 times, as at full size: camera buffer and counters, four seeds
 """
 import importlib
 import json
@@ -64,6 +66,13 @@ MANIFEST = {
     # thin-lens cameras (explicit aperture; aperture from focal length / f-number) and an orthographic one
     "probes_lens": {"scene": "tests/scenes/lens.json"},
     "render_lens": {"scene": "tests/scenes/lens.json", "photons_per_light": 1500, "fetch_size": 50000},
+    # The headline configuration in the regime it runs in at full size: the probes keep 4.3 times the records
+    # the store has room for (there 32.1 M for 7.5 M places; here 640 k for 150 k).  The reference's own
+    # frame with its ten workers, and three more seeds for the spread between reference frames (worker w draws
+    # from mt19937(seed + w), reference src/Renderer.cpp:438-441: seeds closer than the worker count share streams).
+    "render_bombardment_overflow": {"scene": "scenes/MirrorBombardment-200M.json", "photons_per_light": 4000000,
+                                    "image": 160, "seed": 31, "bounce_store_capacity": 150000,
+                                    "spread_seeds": [131, 231, 331]},
 }
 
 WALKS = ("walk_furnace", "walk_mixed", "walk_animated", "walk_singlephoton", "walk_mirrordirect", "walk_cbgmd",
@@ -96,6 +105,8 @@ def write_scene(rt, entry, path):
         s.probe_keep_radius_scale = entry["probe_keep_radius_scale"]
     if "probe_sub_sample" in entry:
         s.probe_sub_sample = entry["probe_sub_sample"]
+    if "bounce_store_capacity" in entry:
+        s.bounce_store_capacity = entry["bounce_store_capacity"]
     if "image" in entry:  # shrink every camera to image x image pixels
         s.image_width = s.image_height = entry["image"]
         for c in range(scene.desc.camera_count):
@@ -182,6 +193,24 @@ def main():
             for k in list(keep):
                 if k.startswith("render_image_c"):
                     keep[k] = keep[k].astype(np.uint16)
+            np.savez_compressed(os.path.join(GOLDEN, key + ".npz"), **keep)
+
+        # ---- a frame whose store overflows: the reference's frame and the spread between such frames ----
+        if wanted("render_bombardment_overflow"):
+            key = "render_bombardment_overflow"
+            keep = {}
+            for n, seed in enumerate([MANIFEST[key]["seed"]] + MANIFEST[key]["spread_seeds"]):
+                scene_path = os.path.join(tmp, f"{key}_{seed}.rtsb")
+                write_scene(rt, dict(MANIFEST[key], seed=seed), scene_path)
+                d = os.path.join(tmp, f"{key}_{seed}")
+                os.makedirs(d)
+                run(REFDUMP, "render", scene_path, d)
+                arrays = load_dir(d)
+                counters = arrays["render_counters"].copy()
+                counters[10] = 0.0  # photonPassSeconds: a wall-clock time
+                prefix = "render" if n == 0 else f"spread{n}"
+                keep[f"{prefix}_buffer_c0"] = arrays["render_buffer_c0"]
+                keep[f"{prefix}_counters"] = counters
             np.savez_compressed(os.path.join(GOLDEN, key + ".npz"), **keep)
 
         # ---- probe pass ----

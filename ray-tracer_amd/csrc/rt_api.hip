@@ -215,8 +215,22 @@ struct rt_tracer
     DeviceArray<rtd::NearEntry> nearEntries;
     rtd::ProbeView probeView{};
     DeviceArray<float> storeRecords;
-    uint64_t storeCapacity = 0;   // records the store takes (rt_set_store_limit may hold it below what is allocated)
-    uint64_t storeAllocated = 0;  // records the store has room for
+    uint64_t storeCapacity = 0;    // records the store takes (rt_set_store_limit may hold it below what was configured)
+    uint64_t storeConfigured = 0;  // the capacity rt_set_probes* was given
+    uint64_t storeAllocated = 0;   // records there is room for while a pass runs: the configured capacity and, where a
+                                   // pass can overflow it, room behind it (rtd::StoreView)
+    DeviceArray<unsigned long long> storeKeys;         // [1 + storeAllocated] rtd::StoreView::keys from [-1] on, or empty
+    DeviceArray<rtd::StoreSelectState> storeSelectState;
+    DeviceArray<uint32_t> storeSelectLists;            // holes, then fillers
+    // A pass that may have overflowed the store and has not been looked at yet (settleStore): the cursor
+    // before it, and how many bits its keys have.
+    bool storePending = false;
+    uint64_t storePassStart = 0;
+    int storePassKeyBits = 1;
+    bool storePassOrdered = false;
+    bool storeCursorKnown = false;  // storeCursorHost is the device's cursor
+    uint64_t storeCursorHost = 0;
+    bool storeOrderWarned = false;
 
     // sink B
     bool splatSet = false;
@@ -877,6 +891,9 @@ void buildScene(rt_tracer* t, const rt_scene* scene)
 
 void resetState(rt_tracer* t)
 {
+    t->storePending = false;
+    t->storeCursorKnown = true;
+    t->storeCursorHost = 0;
     t->scalars.zero(t->stream);
     t->counters.zero(t->stream);
     for (size_t c = 0; c < t->cameraHost.size(); ++c)
@@ -891,6 +908,113 @@ void resetState(rt_tracer* t)
         t->densityPower.zero(t->stream);
         t->densityCount.zero(t->stream);
     }
+}
+
+// bits that hold every value below `count`
+int bitsFor(uint64_t count)
+{
+    int bits = 0;
+    while (bits < 63 && (1ull << bits) < count) ++bits;
+    return bits;
+}
+
+// The store's cursor as the device holds it (waits for the stream unless the host already knows it).
+uint64_t storeCursor(rt_tracer* tracer)
+{
+    if (!tracer->storeCursorKnown)
+    {
+        unsigned long long cursor = 0;
+        check(hipMemcpyAsync(&cursor, tracer->scalars.ptr + 1, sizeof(cursor), hipMemcpyDeviceToHost, tracer->stream),
+              "hipMemcpyAsync store cursor");
+        check(hipStreamSynchronize(tracer->stream), "hipStreamSynchronize");
+        tracer->storeCursorHost = cursor;
+        tracer->storeCursorKnown = true;
+    }
+    return tracer->storeCursorHost;
+}
+
+// After a pass that overflowed the store: the records the reference would hold — the first in the order
+// its workers meet the photons in (rtd::StoreView) — are moved into the capacity.  Everything that reads the
+// store, or appends to it after a pass, comes through here first; a store that did not overflow costs the
+// look at its cursor.  Waits for the stream.
+void settleStore(rt_tracer* tracer)
+{
+    if (!tracer->storePending)
+    {
+        return;
+    }
+    tracer->storePending = false;
+    tracer->storeCursorKnown = false;
+    const uint64_t cursor = storeCursor(tracer);
+    const uint64_t capacity = tracer->storeCapacity, first = tracer->storePassStart;
+    if (cursor <= capacity || first >= capacity)
+    {
+        return;  // nothing was dropped, or the pass found the store full
+    }
+    const uint64_t held = std::min<uint64_t>(cursor, tracer->storePassOrdered ? tracer->storeAllocated : capacity);
+    const uint64_t candidates = held - first, need = capacity - first;
+    const bool verbose = std::getenv("RT_AMD_VERBOSE") != nullptr;
+    if (!tracer->storePassOrdered || candidates <= need)
+    {
+        // no room behind the capacity: the store holds what arrived first, in the device's own order
+        if (!tracer->storeOrderWarned)
+        {
+            std::fprintf(stderr, "[rt_amd] the bounce store overflowed in a pass it had no room to order: it holds the records "
+                                 "that arrived first on the device, not the first in photon order\n");
+            tracer->storeOrderWarned = true;
+        }
+        return;
+    }
+    hipStream_t stream = tracer->stream;
+    if (tracer->storeSelectState.count == 0) tracer->storeSelectState.allocate(1);
+    if (tracer->storeSelectLists.count < 2 * need) tracer->storeSelectLists.allocate(static_cast<size_t>(2 * need));
+    rtd::StoreSelectState* state = tracer->storeSelectState.ptr;
+    uint32_t* holes = tracer->storeSelectLists.ptr;
+    uint32_t* fillers = tracer->storeSelectLists.ptr + need;
+    rtd::launchStoreSelectThreshold(tracer->storeKeys.ptr + 1 + first, candidates, need, tracer->storePassKeyBits, state, stream);
+    rtd::launchStoreSelectClassify(tracer->storeKeys.ptr + 1, first, candidates, capacity, state, holes, fillers, stream);
+    rtd::launchStoreSelectMove(tracer->storeRecords.ptr, tracer->storeKeys.ptr + 1, state, holes, fillers, need, stream);
+    check(hipGetLastError(), "store selection");
+    unsigned long long found[4] = {0, 0, 0, 0};  // prefix, remaining, holes, fillers
+    unsigned long long leastDropped = ~0ull;
+    check(hipMemcpyAsync(found, state, sizeof(found), hipMemcpyDeviceToHost, stream), "hipMemcpyAsync selection");
+    check(hipMemcpyAsync(&leastDropped, tracer->storeKeys.ptr, sizeof(leastDropped), hipMemcpyDeviceToHost, stream),
+          "hipMemcpyAsync selection");
+    check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+    if (verbose)
+    {
+        std::fprintf(stderr, "[rt_amd] store overflow: %llu records of the pass for %llu places, %llu moved in\n",
+                     static_cast<unsigned long long>(candidates), static_cast<unsigned long long>(need), found[3]);
+    }
+    if (found[2] != found[3])
+    {
+        throw ApiError(RT_ERR_STATE, "store selection: " + std::to_string(found[2]) + " records to replace, " +
+                                         std::to_string(found[3]) + " to move in");
+    }
+    if (cursor > tracer->storeAllocated && leastDropped <= found[0] && !tracer->storeOrderWarned)
+    {
+        std::fprintf(stderr, "[rt_amd] the bounce store overflowed its room as well (%llu records for %llu): some of the first "
+                             "records in photon order were dropped\n",
+                     static_cast<unsigned long long>(cursor), static_cast<unsigned long long>(tracer->storeAllocated));
+        tracer->storeOrderWarned = true;
+    }
+}
+
+// What a pass needs to know about the store before it appends: the cursor it starts from (an earlier pass
+// is settled first), the order keys' width.
+void beginStorePass(rt_tracer* tracer, const rtd::TraceArgs& args)
+{
+    settleStore(tracer);
+    tracer->storePassStart = storeCursor(tracer);
+    tracer->storePassOrdered = args.store.keys != nullptr;
+    tracer->storePassKeyBits = args.store.keyBits + std::max(1, bitsFor(args.totalWork));
+    if (tracer->storePassOrdered)
+    {
+        const unsigned long long none = ~0ull;
+        check(hipMemcpyAsync(tracer->storeKeys.ptr, &none, sizeof(none), hipMemcpyHostToDevice, tracer->stream), "hipMemcpyAsync");
+    }
+    tracer->storePending = true;
+    tracer->storeCursorKnown = false;
 }
 
 struct CellKey
@@ -1411,6 +1535,31 @@ int32_t rt_set_stream(rt_tracer* tracer, void* hip_stream)
 namespace
 {
 
+// Deposits the scene's photon budget can make at most: photons x lights x bounces a photon can make.
+uint64_t depositBound(const rt_tracer* tracer)
+{
+    const long double bound = static_cast<long double>(tracer->settings.photons_per_light) *
+                              static_cast<long double>(std::max<int64_t>(1, tracer->lightCount)) *
+                              static_cast<long double>(std::max(0, tracer->settings.bounce_threshold) + 1);
+    return bound >= 1.8e19L ? ~0ull : static_cast<uint64_t>(bound);
+}
+
+uint64_t overflowRoom(const rt_tracer* tracer, uint64_t capacity)
+{
+    if (const char* v = std::getenv("RT_AMD_STORE_ROOM")) return std::strtoull(v, nullptr, 10);  // tests: a given room
+    const uint64_t bound = depositBound(tracer);
+    if (bound < capacity / 4) return 0;  // (the emitters' deposits share the store: a margin for them)
+    size_t freeBytes = 0, totalBytes = 0;
+    if (hipMemGetInfo(&freeBytes, &totalBytes) != hipSuccess) return 0;
+    const uint64_t perRecord = 13 * sizeof(float) + sizeof(unsigned long long);
+    const uint64_t affordable = static_cast<uint64_t>(freeBytes) / 4 / perRecord;
+    uint64_t room = std::min<uint64_t>(bound, std::max<uint64_t>(8 * capacity, 64ull << 20));
+    room = std::min(room, affordable);
+    // slots are 32-bit numbers wherever they are listed
+    const uint64_t slots = (1ull << 32) - 2;
+    return capacity >= slots ? 0 : std::min(room, slots - capacity);
+}
+
 // ProbeIndex's constructor and the BounceStore behind it (reference src/ProbeIndex.cpp:5-25,
 // src/Renderer.cpp:372-392) from `n` positions in host or device memory.
 void setProbes(rt_tracer* tracer, const double* probes, bool probesOnDevice, uint64_t n, double cell_size, double keep_radius,
@@ -1421,9 +1570,18 @@ void setProbes(rt_tracer* tracer, const double* probes, bool probesOnDevice, uin
     const double invCellSize = 1.0 / cellSize;
     const double keepRadius = keep_radius > 0.0 ? keep_radius : 0.0;
     tracer->storeCapacity = store_capacity;
-    tracer->storeAllocated = store_capacity;
+    tracer->storeConfigured = store_capacity;
     tracer->storeVersion += 1;
-    tracer->storeRecords.allocate(static_cast<size_t>(store_capacity) * 13);
+    tracer->storePending = false;
+    tracer->storeCursorKnown = false;
+    // Room behind the capacity for the passes that can overflow it (see rtd::StoreView): as many records as
+    // the scene's photon budget can deposit, within eight capacities (64 Mi records at least) and a quarter
+    // of the memory that is free; none when the budget cannot come near the capacity.
+    const uint64_t room = overflowRoom(tracer, store_capacity);
+    tracer->storeAllocated = store_capacity + room;
+    tracer->storeRecords.allocate(static_cast<size_t>(tracer->storeAllocated) * 13);
+    if (room > 0) tracer->storeKeys.allocate(static_cast<size_t>(tracer->storeAllocated) + 1);
+    else tracer->storeKeys.release();
     // the usual case (one cell of reach, coordinates that pack) is built on the device
     if (buildProbesOnDevice(tracer, probes, probesOnDevice, n, invCellSize, keepRadius))
     {
@@ -1559,12 +1717,10 @@ int32_t rt_set_store_limit(rt_tracer* tracer, uint64_t max_records)
             throw ApiError(RT_ERR_STATE, "rt_set_probes must be called before rt_set_store_limit");
         }
         activate(tracer);
-        const uint64_t limit = (max_records == 0 || max_records > tracer->storeAllocated) ? tracer->storeAllocated : max_records;
+        const uint64_t limit = (max_records == 0 || max_records > tracer->storeConfigured) ? tracer->storeConfigured : max_records;
         // the cursor counts the appends that were tried: a store that was over its old limit holds that limit
-        unsigned long long cursor = 0;
-        check(hipMemcpyAsync(&cursor, tracer->scalars.ptr + 1, sizeof(cursor), hipMemcpyDeviceToHost, tracer->stream),
-              "hipMemcpyAsync store cursor");
-        check(hipStreamSynchronize(tracer->stream), "hipStreamSynchronize");
+        settleStore(tracer);
+        const uint64_t cursor = storeCursor(tracer);
         const uint64_t held = std::min<uint64_t>(cursor, tracer->storeCapacity);
         if (held > limit)
         {
@@ -1573,6 +1729,11 @@ int32_t rt_set_store_limit(rt_tracer* tracer, uint64_t max_records)
         }
         tracer->storeCapacity = limit;
         tracer->storeVersion += 1;
+        // a share of a store that could not overflow as a whole may: what lies behind the limit is its room
+        if (tracer->storeKeys.ptr == nullptr && limit < tracer->storeAllocated && depositBound(tracer) >= limit / 4)
+        {
+            tracer->storeKeys.allocate(static_cast<size_t>(tracer->storeAllocated) + 1);
+        }
     });
 }
 
@@ -1590,7 +1751,11 @@ int32_t rt_deposit_emitters(rt_tracer* tracer, double deposit_spacing, uint64_t*
         DeviceArray<unsigned long long> scalars;  // [0] samples on the patch, [1] kept
         scalars.allocate(2);
         const double spacing = std::max(deposit_spacing, 1e-6);
-        rtd::StoreView store{tracer->storeRecords.ptr, tracer->scalars.ptr + 1, tracer->storeCapacity};
+        settleStore(tracer);
+        // (emitter deposits are laid down before the photons' so that no overflow drops them: they are
+        // ordered among themselves by arrival, with no room behind the capacity)
+        rtd::StoreView store{tracer->storeRecords.ptr, tracer->scalars.ptr + 1, tracer->storeCapacity, nullptr, 0};
+        tracer->storeCursorKnown = false;
         uint64_t sampleTotal = 0, keptTotal = 0;
         // Into an empty store, with the probes and the spacing of the last run: the same records again
         // (their order in the store is the schedule's, then as now).  (RT_AMD_EMITTER_CACHE=0: always anew)
@@ -1614,6 +1779,8 @@ int32_t rt_deposit_emitters(rt_tracer* tracer, double deposit_spacing, uint64_t*
                       "hipMemcpyAsync cursor");
                 check(hipStreamSynchronize(stream), "hipStreamSynchronize");
             }
+            tracer->storeCursorHost = last.kept;
+            tracer->storeCursorKnown = true;
             if (samples != nullptr) *samples = last.samples;
             if (kept != nullptr) *kept = last.kept;
             return;
@@ -1690,6 +1857,8 @@ int32_t rt_deposit_emitters(rt_tracer* tracer, double deposit_spacing, uint64_t*
             last.probeVersion = tracer->probeVersion;
             last.spacing = spacing;
         }
+        tracer->storeCursorHost = cursorBefore + keptTotal;
+        tracer->storeCursorKnown = true;
         if (samples != nullptr) *samples = sampleTotal;
         if (kept != nullptr) *kept = keptTotal;
     });
@@ -1794,7 +1963,13 @@ rtd::TraceArgs passArguments(const rt_tracer* tracer, const rt_trace_params* par
     args.probes = tracer->probeView;
     args.store.records = tracer->storeRecords.ptr;
     args.store.cursor = tracer->scalars.ptr + 1;
-    args.store.capacity = tracer->storeCapacity;
+    // the store takes records into the room behind its capacity when it has order keys to settle them by
+    const int bounceBits = bitsFor(static_cast<uint64_t>(std::max(0, tracer->settings.bounce_threshold)) + 1);
+    const uint64_t ids = count * static_cast<uint64_t>(std::max<int64_t>(1, tracer->lightCount));
+    const bool ordered = tracer->storeKeys.ptr != nullptr && tracer->storeAllocated > tracer->storeCapacity && ids < (1ull << 32);
+    args.store.room = ordered ? tracer->storeAllocated : tracer->storeCapacity;
+    args.store.keys = ordered ? tracer->storeKeys.ptr + 1 : nullptr;
+    args.store.keyBits = bounceBits;
     args.density = tracer->densityView;
     args.counters = tracer->counters.ptr;
     args.workCounter = tracer->scalars.ptr;
@@ -1850,6 +2025,7 @@ int32_t rt_trace(rt_tracer* tracer, const rt_trace_params* params)
         resolveRange(tracer, params, &first, &count);
         requireSink(tracer, params);
         rtd::TraceArgs args = passArguments(tracer, params, first, count);
+        if (params->sink_mode == RT_SINK_PROBE) beginStorePass(tracer, args);
 
         const int32_t maxBounces = tracer->settings.bounce_threshold + 1;
         const uint64_t record = std::min<uint64_t>(params->record_photons, args.totalWork);
@@ -2160,6 +2336,7 @@ int32_t rt_trace_static(rt_tracer* tracer, const rt_trace_params* params)
                                              " bytes of work space, the static scratch reserves " +
                                              std::to_string(kStaticSortBytes));
         }
+        if (params->sink_mode == RT_SINK_PROBE) beginStorePass(tracer, args);  // (allocates nothing)
         tracer->recordPhotons = 0;  // the buffers of an earlier rt_trace stay allocated and are not read
         tracer->timed = false;
         tracer->orderedLength = 0;  // this pass's order lives in the static array
@@ -2387,9 +2564,9 @@ int32_t rt_read_store(rt_tracer* tracer, float* records, uint64_t max_records, u
     return guarded([&]() {
         require(tracer != nullptr && count != nullptr, "null argument");
         activate(tracer);
+        settleStore(tracer);
+        const uint64_t cursor = storeCursor(tracer);
         check(hipStreamSynchronize(tracer->stream), "hipStreamSynchronize");
-        unsigned long long cursor = 0;
-        check(hipMemcpy(&cursor, tracer->scalars.ptr + 1, sizeof(cursor), hipMemcpyDeviceToHost), "hipMemcpy cursor");
         const uint64_t size = std::min<uint64_t>(cursor, tracer->storeCapacity);
         *count = size;
         const uint64_t n = std::min(size, max_records);
@@ -2530,9 +2707,9 @@ int32_t rt_store_append(rt_tracer* tracer, const float* records13, uint64_t n)
         activate(tracer);
         // BounceStore::append n times (reference src/BounceStore.cpp:11-20): the cursor always
         // advances, records beyond the capacity are dropped
+        settleStore(tracer);
+        unsigned long long cursor = storeCursor(tracer);
         check(hipStreamSynchronize(tracer->stream), "hipStreamSynchronize");
-        unsigned long long cursor = 0;
-        check(hipMemcpy(&cursor, tracer->scalars.ptr + 1, sizeof(cursor), hipMemcpyDeviceToHost), "hipMemcpy cursor");
         const uint64_t room = cursor < tracer->storeCapacity ? tracer->storeCapacity - cursor : 0;
         const uint64_t fit = std::min<uint64_t>(room, n);
         if (fit > 0)
@@ -2543,6 +2720,8 @@ int32_t rt_store_append(rt_tracer* tracer, const float* records13, uint64_t n)
         }
         cursor += n;
         check(hipMemcpy(tracer->scalars.ptr + 1, &cursor, sizeof(cursor), hipMemcpyHostToDevice), "hipMemcpy cursor");
+        tracer->storeCursorHost = cursor;
+        tracer->storeCursorKnown = true;
     });
 }
 
@@ -2558,9 +2737,8 @@ int32_t rt_gather(rt_tracer* tracer, int32_t camera, double gather_cell_size, do
         }
         activate(tracer);
         rt_tracer::GatherCache& cache = ensureGatherPoints(tracer, camera);
-        check(hipStreamSynchronize(tracer->stream), "hipStreamSynchronize");
-        unsigned long long cursor = 0;
-        check(hipMemcpy(&cursor, tracer->scalars.ptr + 1, sizeof(cursor), hipMemcpyDeviceToHost), "hipMemcpy cursor");
+        settleStore(tracer);
+        const uint64_t cursor = storeCursor(tracer);
         const uint64_t n = std::min<uint64_t>(cursor, tracer->storeCapacity);
         require(n < (1ull << 31), "bounce store too large for the gather index");
         const double cellSize = gather_cell_size > 0.0 ? gather_cell_size : 1.0;  // reference src/BounceStore.cpp:44

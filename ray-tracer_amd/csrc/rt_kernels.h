@@ -47,11 +47,23 @@ struct alignas(16) NearEntry
     uint32_t bits, reserved;
 };
 
+// The store drops what arrives beyond its capacity (reference src/BounceStore.cpp:21-33), and which
+// records those are is decided by the order the reference's workers meet the photons in: index order,
+// light by light (reference src/Worker.cpp:429-505).  The device traces photons in an order of its own, so
+// a store that overflows keeps taking records — into room behind its capacity, with each record's place
+// in the reference's order beside it (`keys`) — and when the pass is over the records that come first in
+// that order are moved into the capacity (launchStoreSelect*).  `room` is the capacity and `keys` null
+// where no pass can overflow the store: then a record beyond the capacity is dropped on arrival.
 struct StoreView
 {
-    float* records;                  // [capacity][13]
-    unsigned long long* cursor;      // claimed slots, may exceed capacity
-    uint64_t capacity;
+    float* records;                  // [room][13]
+    unsigned long long* cursor;      // claimed slots, may exceed room
+    uint64_t room;                   // records there is room for while a pass runs: the capacity, or more (see above)
+    // null, or [-1 .. room): the key of the record in each slot — the photon's number in the pass (light x
+    // photons per light + index - first index, below 2^32) above `keyBits` bits of bounce — and, at [-1], the
+    // least key among the records that found no room at all
+    unsigned long long* keys;
+    int32_t keyBits;
 };
 
 // Sink B density grid (reference src/DensityGrid.cpp): one 64-bit packed cell key per
@@ -287,5 +299,28 @@ void launchNeighbourKeys(const unsigned long long* sortedKeys, uint64_t n, unsig
 void launchNeighbourTable(const unsigned long long* sortedKeys, const uint32_t* sortedBits, uint64_t n,
                           NearEntry* nearEntries, uint64_t nearMask, hipStream_t stream);
 void launchProbeTest(const ProbeView& probes, int64_t n, const double* points, uint8_t* out, hipStream_t stream);
+
+// ---- which records an overflowing store keeps (rt_store.hip) ----
+// A pass left `candidates` records with keys[0 .. candidates) (all different), of which the `need` with
+// the smallest keys are wanted.  StoreSelectState is the device-side state of that selection.
+constexpr int kSelectDigitBits = 10;
+struct StoreSelectState
+{
+    unsigned long long prefix;     // the leading bits of the need-th smallest key found so far
+    unsigned long long remaining;  // how many keys with that prefix, counted from the smallest, are still wanted
+    unsigned long long holes, fillers;  // records to replace inside the capacity / to move in from behind it
+    unsigned int histogram[1 << kSelectDigitBits];
+};
+// Finds the need-th smallest of keys[0 .. candidates) (1 <= need <= candidates), digit by digit from bit
+// `bits` - 1 down: state->prefix holds it afterwards.  Resets the state first.
+void launchStoreSelectThreshold(const unsigned long long* keys, uint64_t candidates, uint64_t need, int bits,
+                                StoreSelectState* state, hipStream_t stream);
+// Records are at slots first .. first + candidates; those at slots below `capacity` whose key exceeds the
+// threshold are listed in holes, those at slots from `capacity` on whose key does not in fillers (as many).
+void launchStoreSelectClassify(const unsigned long long* keys, uint64_t first, uint64_t candidates, uint64_t capacity,
+                               StoreSelectState* state, uint32_t* holes, uint32_t* fillers, hipStream_t stream);
+// records[holes[i]] = records[fillers[i]] for every pair (keys likewise); `pairs` is an upper bound of their number
+void launchStoreSelectMove(float* records, unsigned long long* keys, const StoreSelectState* state, const uint32_t* holes,
+                           const uint32_t* fillers, uint64_t pairs, hipStream_t stream);
 
 }  // namespace rtd

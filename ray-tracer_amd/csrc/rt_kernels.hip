@@ -295,8 +295,23 @@ RT_DEV bool anyProbeWithin(const ProbeView& pv, const Vec& p)
 // BounceStore::append, reference src/BounceStore.cpp:11-20, with the cursor claimed
 // once per wave: the lanes that append in this step count themselves with a ballot,
 // one lane adds the total, each lane takes base + its rank.
+// A record's place in the order the reference's workers meet the photons in — light by light, index by
+// index, bounce by bounce — as one number: what an overflowing store is put in order by.  The photon's
+// number in the pass (light x photons per light + index - first index: 32 bits, larger passes are not
+// ordered) sits above StoreView::keyBits bits of bounce.
+struct StoreOrder
+{
+    uint32_t photonIndexLow, firstPhotonLow, photonsPerLightLow;  // low words: the pass holds fewer than 2^32 ids
+    int lightId, bounces;
+    RT_DEV unsigned long long key(const StoreView& sv) const
+    {
+        const uint32_t idInPass = static_cast<uint32_t>(lightId) * photonsPerLightLow + (photonIndexLow - firstPhotonLow);
+        return (static_cast<unsigned long long>(idInPass) << sv.keyBits) | static_cast<unsigned long long>(bounces);
+    }
+};
+
 RT_DEV void storeAppend(const StoreView& sv, bool keep, const Vec& position, const Vec& incoming, const Vec& normal,
-                        float time, const Color& power)
+                        float time, const Color& power, const StoreOrder& order)
 {
     const unsigned long long mask = __ballot(keep);
     if (mask == 0)
@@ -313,7 +328,7 @@ RT_DEV void storeAppend(const StoreView& sv, bool keep, const Vec& position, con
     if (keep)
     {
         const unsigned long long slot = base + lanesBelow(mask);
-        if (slot < sv.capacity)
+        if (slot < sv.room)
         {
             // 52-byte records are only 4-byte aligned; the hardware takes unaligned 16-byte stores,
             // so a record is three of them and one float instead of thirteen floats
@@ -336,6 +351,11 @@ RT_DEV void storeAppend(const StoreView& sv, bool keep, const Vec& position, con
             *reinterpret_cast<UnalignedFloat4*>(r + 4) = q1;
             *reinterpret_cast<UnalignedFloat4*>(r + 8) = q2;
             r[12] = power.b;
+            if (sv.keys) sv.keys[slot] = order.key(sv);
+        }
+        else if (sv.keys)
+        {
+            atomicMin(sv.keys - 1, order.key(sv));
         }
     }
 }
@@ -644,7 +664,7 @@ RT_DEV uint32_t rayKey(const TraceArgs& a, const Ray& ray)
 // Sink selects the deposit path and Record the per-photon path dump at compile time, so
 // that the probe-sink kernel carries neither the splat's shadow-ray cast nor the dump.
 template <int Sink, bool Record, bool Animated>
-__global__ __launch_bounds__(kTraceThreads) void traceKernel(const TraceArgs a)
+__global__ __launch_bounds__(kTraceThreads) __attribute__((amdgpu_waves_per_eu((Animated && !Record) ? 2 : 1))) void traceKernel(const TraceArgs a)
 {
     const SceneView& s = a.scene;
     const int lane = threadIdx.x & 63;
@@ -856,7 +876,9 @@ __global__ __launch_bounds__(kTraceThreads) void traceKernel(const TraceArgs a)
                         tally(lc, kTallyKept, keep);
                         tally(lc, kTallyCulled, !keep);
                     }
-                    storeAppend(a.store, keep, hit.position, ray.d, hit.normal, time, color);
+                    storeAppend(a.store, keep, hit.position, ray.d, hit.normal, time, color,
+                                StoreOrder{static_cast<uint32_t>(photonIndex), static_cast<uint32_t>(a.firstPhoton),
+                                           static_cast<uint32_t>(a.photonCount), lightId, bounces});
                 }
                 else if (Sink == kSinkSplat)
                 {
@@ -2343,7 +2365,7 @@ __global__ void emitterDepositKernel(const EmitterGrid g, const ProbeView probes
         const bool keep = i < total && emitterSample(g, i, &p) && anyProbeWithin(probes, p);
         const Vec n = mk(g.normal[0], g.normal[1], g.normal[2]);
         // incoming direction = normal, time = +inf: a timeless deposit (reference :528-541)
-        storeAppend(store, keep, p, n, n, __builtin_inff(), Color{g.power[0], g.power[1], g.power[2]});
+        storeAppend(store, keep, p, n, n, __builtin_inff(), Color{g.power[0], g.power[1], g.power[2]}, StoreOrder{0, 0, 0, 0, 0});
         if (keep) mine += 1;
     }
     mine = waveSum(mine);

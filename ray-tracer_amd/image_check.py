@@ -81,6 +81,29 @@ def rel_rmse(got, want):
     return float(np.sqrt(((got - want) ** 2).mean()) / scale) if scale > 0 else float(np.abs(got).max())
 
 
+def lit_box(buffers):
+    """(y0, y1, x0, x1), ends exclusive, of the pixels any of the [h, w, 3] buffers lights."""
+    lit = np.zeros(np.asarray(buffers[0]).shape[:2], dtype=bool)
+    for b in buffers:
+        lit |= np.asarray(b).sum(axis=2) > 0
+    ys, xs = np.nonzero(lit)
+    return (int(ys.min()), int(ys.max()) + 1, int(xs.min()), int(xs.max()) + 1) if ys.size else (0, 0, 0, 0)
+
+
+def regional_means(buffer, box, grid=4):
+    """Mean of a [h, w, 3] buffer over each cell of a grid x grid partition of `box` (see lit_box): [grid, grid]."""
+    y0, y1, x0, x1 = box
+    b = np.asarray(buffer, dtype=np.float64).sum(axis=2)
+    ys = np.linspace(y0, y1, grid + 1).round().astype(int)
+    xs = np.linspace(x0, x1, grid + 1).round().astype(int)
+    out = np.zeros((grid, grid))
+    for i in range(grid):
+        for j in range(grid):
+            cell = b[ys[i]:ys[i + 1], xs[j]:xs[j + 1]]
+            out[i, j] = cell.mean() if cell.size else 0.0
+    return out
+
+
 def main(argv):
     if len(argv) < 2:
         print(__doc__)

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 import oracle_lib as O
-from conftest import REPO, assert_bits_equal
+from conftest import REPO, assert_bits_equal, assert_one_more_frame
 
 pytestmark = pytest.mark.gpu
 
@@ -251,13 +251,100 @@ def test_probe_sink_store_equals_oracle(rt, scene_opener, name):
     for k in ("kept", "culled", "store_attempted", "store_size", "store_dropped", "deposits"):
         assert c[k] == ref[k], k
     assert_bits_equal(_sorted_records(tracer.store()), _sorted_records(ref["store"]), "store records")
-    # overflow: capacity below the kept count drops the excess and reports it
+    # overflow: capacity below the kept count drops the excess and reports it.  WHICH records a full
+    # store holds is decided by the order the reference's workers meet the photons in — index order,
+    # light by light (reference src/Worker.cpp:429-505, src/BounceStore.cpp:11-33) —, which is the order
+    # of the oracle's single thread: the device, whatever order it traces in, must end up with exactly
+    # those records.
     small = max(1, ref["kept"] // 3)
+    first = orc.trace(rng_mode=O.RNG_COUNTER, math_mode=O.MATH_PORTABLE, threads=1, sink_mode=O.SINK_PROBE,
+                      probes=probes, probe_cell_size=keep, keep_radius=keep, store_capacity=small)
+    assert first["store_size"] == small and first["store_dropped"] == ref["kept"] - small
     tracer.set_probes(probes, keep, keep, small)
     tracer.reset()
     tracer.trace(sink_mode=1)
     c = tracer.counters()
     assert c["store_size"] == small and c["store_dropped"] == ref["kept"] - small and c["store_attempted"] == ref["kept"]
+    assert_bits_equal(_sorted_records(tracer.store()), _sorted_records(first["store"]), "records of the overflowing store")
+
+
+@pytest.mark.parametrize("variant", ["one pass", "two passes", "bounce levels", "radix order", "preloaded"])
+def test_overflowing_store_holds_the_first_records_in_photon_order(rt, scene_opener, variant, monkeypatch):
+    """The headline configuration's regime: the probes keep several times the records the store has room
+    for (MirrorBombardment-200M keeps 32 M for 7.5 M places).  The reference's store then holds the
+    deposits of the photons its workers met first, i.e. of the lowest indices — a fair sample of the
+    emission directions.  The device traces in emission order, run by run, so what ARRIVES first is
+    anything but: it takes the overflow into room behind the capacity and settles it by photon order
+    afterwards.  The oracle's single thread walks the photons in the reference's order; the stores must
+    hold the same records bit for bit — also when the pass is split in two ranges, goes through the
+    bounce-level queues or the radix-sorted schedule, or starts on a store that already holds records."""
+    if variant == "bounce levels":
+        monkeypatch.setenv("RT_AMD_QUEUE_MIN", "1")
+        monkeypatch.setenv("RT_AMD_LEVEL_SORT_MIN", "1")
+    if variant == "radix order":
+        monkeypatch.setenv("RT_AMD_EMISSION_SORT", "radix")
+    photons = 300_000
+    name = "cbgmd" if variant == "bounce levels" else "bombardment"
+    entry = dict(SCENES[name], photons_per_light=photons)
+    scene, tracer, orc = _open(rt, scene_opener, entry)
+    pre = orc.trace(rng_mode=O.RNG_COUNTER, math_mode=O.MATH_PORTABLE, threads=8, record_photons=4000)
+    probes = pre["bounce_f64"][:, 0, :3][pre["casts_valid"][:, 1] > 0][::2]
+    extent = np.ptp(probes, axis=0).max()
+    keep = float(extent) / 40.0
+    whole = orc.trace(rng_mode=O.RNG_COUNTER, math_mode=O.MATH_PORTABLE, threads=8, sink_mode=O.SINK_PROBE,
+                      probes=probes, probe_cell_size=keep, keep_radius=keep, store_capacity=1 << 24)
+    preload = whole["store"][:777].copy() if variant == "preloaded" else None
+    capacity = max(1000, whole["kept"] // 4) + (777 if preload is not None else 0)
+    assert whole["kept"] > 4000
+    want = orc.trace(rng_mode=O.RNG_COUNTER, math_mode=O.MATH_PORTABLE, threads=1, sink_mode=O.SINK_PROBE, probes=probes,
+                     probe_cell_size=keep, keep_radius=keep, store_capacity=capacity, preload=preload)
+    tracer.set_probes(probes, keep, keep, capacity)
+    tracer.reset()
+    if preload is not None:
+        tracer.store_append(preload)
+    if variant == "two passes":
+        tracer.trace(sink_mode=1, first_photon=0, photon_count=photons // 5)
+        tracer.trace(sink_mode=1, first_photon=photons // 5, photon_count=photons - photons // 5)
+    else:
+        tracer.trace(sink_mode=1)
+    c = tracer.counters()
+    for k in ("kept", "culled", "store_attempted", "store_size", "store_dropped"):
+        assert c[k] == want[k], k
+    assert c["store_size"] == capacity and c["store_dropped"] > 2 * capacity
+    got = tracer.store()
+    assert_bits_equal(_sorted_records(got), _sorted_records(want["store"]), "records of the overflowing store")
+    if preload is not None:  # what was there before the pass stays where it was
+        assert_bits_equal(got[:777], preload, "preloaded records")
+    # and the survivors are spread over the whole emission domain, not bunched where the device happened
+    # to start: the centroid of the kept records is the centroid of everything the probes keep
+    everything = whole["store"][:whole["store_size"], :3].astype(np.float64)
+    held = got[(777 if preload is not None else 0):, :3].astype(np.float64)
+    spread = everything.std(axis=0).max()
+    assert np.abs(held.mean(axis=0) - everything.mean(axis=0)).max() < 0.05 * spread
+
+
+def test_store_overflowing_its_room_too_still_counts_right(rt, scene_opener, monkeypatch, capfd):
+    """RT_AMD_STORE_ROOM holds the room behind the capacity down to a few records: the pass overflows
+    that as well.  The counters stay exact, the store is full, and the library says on stderr that the
+    survivors are no longer the first in photon order."""
+    monkeypatch.setenv("RT_AMD_STORE_ROOM", "64")
+    entry = dict(SCENES["bombardment"], photons_per_light=60_000)
+    scene, tracer, orc = _open(rt, scene_opener, entry)
+    pre = orc.trace(rng_mode=O.RNG_COUNTER, math_mode=O.MATH_PORTABLE, threads=8, record_photons=2000)
+    probes = pre["bounce_f64"][:, 0, :3][pre["casts_valid"][:, 1] > 0][::2]
+    keep = float(np.ptp(probes, axis=0).max()) / 40.0
+    want = orc.trace(rng_mode=O.RNG_COUNTER, math_mode=O.MATH_PORTABLE, threads=1, sink_mode=O.SINK_PROBE, probes=probes,
+                     probe_cell_size=keep, keep_radius=keep, store_capacity=500)
+    assert want["store_dropped"] > 1000
+    tracer.set_probes(probes, keep, keep, 500)
+    tracer.reset()
+    tracer.trace(sink_mode=1)
+    store = tracer.store()
+    c = tracer.counters()
+    for k in ("kept", "store_attempted", "store_size", "store_dropped"):
+        assert c[k] == want[k], k
+    assert store.shape[0] == 500 and np.isfinite(store[:, :9]).all()
+    assert "overflowed its room as well" in capfd.readouterr().err
 
 
 def _philox_first_block(seed, light, photon):
@@ -674,6 +761,70 @@ def test_frame_statistically_equal_to_reference_frame(rt, golden, manifest, scen
     assert reference.sum() > 0 and spread > 0
     assert image_check.rel_rmse(device, reference) <= 1.25 * spread
     assert abs(float(device.sum()) - np.mean(energies)) <= 0.05 * np.mean(energies)
+
+
+def _device_frame(rt, scene, setup, ranks, monkeypatch=None):
+    """The probe-mode frame of `scene` on this GPU: `ranks` tracers, each with its share of the photons and
+    of the frame's one store (rt_set_store_limit), emitter deposits on the first; the ranks' buffers added."""
+    keep = setup["keep_radius"]
+    photons = int(scene.settings.photons_per_light)
+    total, counters = None, []
+    for rank in range(ranks):
+        tracer = rt.Tracer(scene)
+        _, capacity = tracer.set_probes_from_cameras(keep, keep, 256, int(scene.settings.bounce_store_capacity))
+        tracer.reset()
+        _, emitters = tracer.deposit_emitters(setup["emitter_spacing"])
+        if ranks > 1:
+            tracer.reset()
+            rest = capacity - min(emitters, capacity)
+            tracer.set_store_limit(max(1, (min(emitters, capacity) if rank == 0 else 0) + (rest + ranks - 1) // ranks))
+            if rank == 0:
+                tracer.deposit_emitters(setup["emitter_spacing"])
+        first, last = photons * rank // ranks, photons * (rank + 1) // ranks
+        tracer.trace(sink_mode=1, first_photon=first, photon_count=last - first)
+        tracer.gather(0, setup["gather_cell"], setup["min_gather_radius"])
+        frame = tracer.camera_buffer(0).astype(np.float64)
+        total = frame if total is None else total + frame
+        counters.append(tracer.counters())
+        tracer.close()
+    return total, counters
+
+
+@pytest.mark.parametrize("variant", ["one rank", "two ranks", "radix order", "bounce levels"])
+def test_overflowing_headline_frame_against_the_reference_frame(rt, golden, manifest, scene_opener, variant, monkeypatch):
+    """MirrorBombardment-200M runs with a store that overflows 4.3 times (32.1 M deposits kept by the probes
+    for 7.5 M places), so its image is decided by WHICH deposits the store holds.  The fixture is the
+    reference's own frame (Renderer::renderFrame, ten workers) of that scene at 160 x 160 with 4 M photons
+    and a store of 150 000 records — the same 4.3-fold overflow — plus three frames of other seeds.
+    The device's frame, on one rank and on two ranks that share the store, through the radix-sorted
+    schedule and through the bounce-level queues, has to be one more such frame:
+      * relative RMSE against each reference frame <= 1.25 x the largest among the reference frames,
+      * total energy within four times their spread around their mean (the store holds exactly its
+        capacity on both sides, so the energy hardly varies: 0.05 % between seeds),
+      * on a 4 x 4 grid over the lit part of the image, every cell's mean within four times the
+        reference frames' largest deviation from their mean in that cell — a schedule that filled the
+        store from one side of the light's cone would show here.
+    Reference: src/BounceStore.cpp:11-33 (appends beyond the capacity are dropped),
+    src/Worker.cpp:429-505 (workers take the photons in index order), src/Renderer.cpp:382-390,653-667."""
+    image_check = __import__("importlib").import_module("ray-tracer_amd.image_check")
+    key = "render_bombardment_overflow"
+    g, entry = golden(key), dict(manifest[key])
+    references = [g["render_buffer_c0"].astype(np.float64)] + [g[f"spread{i}_buffer_c0"].astype(np.float64) for i in (1, 2, 3)]
+    assert g["render_counters"][4] == entry["bounce_store_capacity"]          # the reference's store is full ...
+    assert g["render_counters"][3] > 4.2 * entry["bounce_store_capacity"]    # ... 4.3 times over
+    if variant == "radix order":
+        monkeypatch.setenv("RT_AMD_EMISSION_SORT", "radix")
+    if variant == "bounce levels":
+        monkeypatch.setenv("RT_AMD_QUEUE_MIN", "1")
+    scene, _, orc = _open(rt, scene_opener, entry)
+    setup = O.frame_setup(orc, O.RNG_COUNTER, O.MATH_PORTABLE)
+    device, counters = _device_frame(rt, scene, setup, 2 if variant == "two ranks" else 1)
+    attempted = sum(c["store_attempted"] for c in counters)
+    held = sum(c["store_size"] for c in counters)
+    assert abs(attempted / g["render_counters"][3] - 1.0) < 0.01   # as many deposits kept by the probes
+    assert entry["bounce_store_capacity"] <= held <= entry["bounce_store_capacity"] + 1
+
+    assert_one_more_frame(device, references)
 
 
 @pytest.mark.parametrize("name", ["mixed", "multicam", "cbgmd", "animated", "stochastic128"])

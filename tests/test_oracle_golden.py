@@ -250,3 +250,32 @@ def test_whole_probe_mode_frame_matches_reference(golden, manifest, scene_opener
         assert_bits_equal(got, want, f"{key} camera {c} buffer")
         image = O.tonemap(got, float(g[f"render_gather_c{c}"][3]))
         assert np.array_equal(image, g[f"render_image_c{c}"]), "tonemapped image"
+
+
+def test_first_records_in_photon_order_make_a_reference_frame(golden, manifest, scene_opener):
+    """A store that overflows holds, in the reference, the deposits of the photons its workers met first
+    (reference src/BounceStore.cpp:11-33, src/Worker.cpp:429-505).  With ten workers on batches of 100 000
+    that is "the lowest photon indices" up to a ragged edge.  The oracle's single thread keeps exactly the
+    first records in photon order; its frame of the overflowing headline scene (store 4.3 times over, as at
+    full size) must be statistically one more of the reference's frames — which is what entitles the device
+    to settle an overflow by photon order (tests/test_gpu_parity.py compares its store with this one bit
+    for bit, and its frame with the same fixture)."""
+    from conftest import assert_one_more_frame
+    key = "render_bombardment_overflow"
+    g, entry = golden(key), dict(manifest[key])
+    references = [g["render_buffer_c0"].astype(np.float64)] + [g[f"spread{i}_buffer_c0"].astype(np.float64) for i in (1, 2, 3)]
+    for name in ("render_counters", "spread1_counters", "spread2_counters", "spread3_counters"):
+        assert g[name][4] == g[name][5] == entry["bounce_store_capacity"]    # store size == capacity: full ...
+        assert 4.2 < g[name][3] / g[name][5] < 4.35                           # ... attempted / capacity
+    scene = scene_opener(entry)
+    orc = O.Oracle(scene)
+    setup = O.frame_setup(orc, O.RNG_COUNTER, O.MATH_PORTABLE)
+    assert setup["store_capacity"] == entry["bounce_store_capacity"]
+    keep = setup["keep_radius"]
+    # the store fills up within the first quarter of the photons: no later photon can change it
+    r = orc.trace(rng_mode=O.RNG_COUNTER, math_mode=O.MATH_PORTABLE, sink_mode=O.SINK_PROBE, threads=1, probes=setup["probes"],
+                  probe_cell_size=keep, keep_radius=keep, store_capacity=setup["store_capacity"],
+                  photon_count=entry["photons_per_light"] * 3 // 10)
+    assert r["store_size"] == setup["store_capacity"] and r["store_dropped"] > 0
+    frame, _ = orc.gather(0, r["store"], setup["gather_cell"], setup["min_gather_radius"])
+    assert_one_more_frame(frame.astype(np.float64), references)
