@@ -19,14 +19,15 @@ The metric counts ray casts that produced a valid hit (photon-bounces) over whol
 
 Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel, traceKernel.  Its duration is
 measured live with HIP events the library records on the tracer's stream around that kernel
-(rt_read_timings).  The kernel is bound by vector-instruction issue (FP64 arithmetic with individually
-rounded operations, two waves per SIMD), not by HBM: `achieved` is the number of cycles per second in
-which the chip's SIMDs execute vector instructions — the per-launch count of the SQ_ACTIVE_INST_VALU
-counter measured by rocprofv3 for exactly this workload (profiles/counters.json) over the live kernel
-time — against the cycles all 1024 SIMDs offer at 2.4 GHz.  `traffic` is the HBM byte count of one
-launch from the FETCH_SIZE / WRITE_SIZE passes of the same profile.  The HBM-priced figure of the
-path's algorithmic bytes is kept under `algorithmic`: for a scene that lives in cache it exceeds the
-HBM peak and is no roofline.
+(rt_read_timings).  The kernel is bound by double-precision vector arithmetic (individually rounded
+operations, two waves per SIMD), not by HBM: `achieved` is the path's algorithmic FP64 operations —
+per cast and volume 150 for the transforms, 30 per slab test at two per level of a balanced tree, 90 per
+triangle test at two per mesh (algorithmic_flops_per_cast) — times the casts of a launch, over the live
+kernel time, against the vector units' FP64 rate without fused multiply-adds.  `valu_busy` is the share
+of all SIMD cycles that issued a vector instruction (SQ_ACTIVE_INST_VALU of the committed rocprofv3
+record of exactly this workload, profiles/counters.json) and `traffic` the HBM bytes of one launch from
+the FETCH_SIZE / WRITE_SIZE passes of the same record.  The HBM-priced figure of the path's algorithmic
+bytes is kept under `algorithmic`: for a scene that lives in cache it exceeds the HBM peak and is no roofline.
 """
 import argparse
 import importlib
@@ -47,6 +48,10 @@ for p in (REPO, os.path.join(REPO, "tests")):
 SCENE = os.path.join(REPO, "scenes", "MirrorBombardment-200M.json")
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
 SIMDS, CLOCK_GHZ = 1024, 2.4   # 256 CUs x 4 SIMDs, peak shader clock
+# FP64 vector peak of the MI355X data sheet, 78.6 TFLOP/s, counts a fused multiply-add as two operations.
+# This path may not fuse (its products are rounded one by one, as the reference's are: -ffp-contract=off),
+# so what the vector units can deliver here is one operation per lane and cycle: half of that.
+FP64_VECTOR_PEAK_TFLOPS = 78.6 / 2
 COUNTER_NAMES = ("photons", "casts", "bounces", "deposits", "kept", "culled", "store_attempted", "store_size",
                  "store_dropped", "splat_total", "density_dropped")
 
@@ -62,6 +67,24 @@ def algorithmic_bytes_per_cast(desc):
             tris = max(1, desc.meshes[vol.mesh].triangle_count)
             depth = max(1, math.ceil(math.log2(tris)))
             total += 2 * depth * 56 + 2 * 72
+    return total
+
+
+def algorithmic_flops_per_cast(desc):
+    """Double-precision operations one scene cast needs by the path's own arithmetic, whatever the tree
+    walked: per volume the ray's transform into object space and the hit's way back (150), per mesh volume
+    two slab tests per level of a balanced tree over its triangles (30 each) and two watertight triangle
+    tests (90 each); an analytic volume (sphere, quad, plane) one intersection (40)."""
+    total = 0.0
+    for v in range(desc.volume_count):
+        vol = desc.volumes[v]
+        total += 150.0
+        if vol.type == 0:
+            tris = max(1, desc.meshes[vol.mesh].triangle_count)
+            depth = max(1, math.ceil(math.log2(tris)))
+            total += 2 * depth * 30 + 2 * 90
+        else:
+            total += 40.0
     return total
 
 
@@ -311,15 +334,22 @@ def main():
         avg_sort_ms = sum(sort_ms) / max(1, len(sort_ms))
         pmc = committed_counters(workload, sink, count * lights)
 
-        # vector-issue roofline of the trace kernel
-        roofline = {"bound": "fp64-valu-issue", "achieved": None, "peak": SIMDS * CLOCK_GHZ, "unit": "Gcycle/s", "frac": None,
+        # Roofline of the trace kernel: the path's algorithmic double-precision operations over the kernel's
+        # measured time, against the vector units' non-fused FP64 rate.  (The share of SIMD cycles that issue
+        # a vector instruction, from the committed counter record of this workload, is kept as `valu_busy`: a
+        # utilisation, not a bound — a kernel that issued more instructions per cast would score higher.)
+        flops_per_cast = algorithmic_flops_per_cast(desc)
+        launch_casts = local["casts"] + (local["splat_total"] if sink == "splat" else 0)  # a splat casts a shadow ray
+        roofline = {"bound": "fp64-vector", "achieved": None, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None,
                     "traffic": None, "kernel": "traceKernel", "kernel_ms": 1e3 * avg_kernel_s, "sort_kernels_ms": avg_sort_ms,
-                    "counters": None}
+                    "flops_per_cast": flops_per_cast, "casts_per_launch": launch_casts, "valu_busy": None, "counters": None}
         hbm = None
+        if avg_kernel_s > 0:
+            achieved = flops_per_cast * launch_casts / avg_kernel_s / 1e12
+            roofline.update(achieved=achieved, frac=achieved / FP64_VECTOR_PEAK_TFLOPS)
         if pmc is not None and avg_kernel_s > 0:
             busy_cycles = 4.0 * pmc["SQ_ACTIVE_INST_VALU"]  # the counter ticks once per four cycles
-            achieved = busy_cycles / avg_kernel_s / 1e9
-            roofline.update(achieved=achieved, frac=achieved / (SIMDS * CLOCK_GHZ), traffic=pmc["hbm_bytes"],
+            roofline.update(valu_busy=busy_cycles / avg_kernel_s / 1e9 / (SIMDS * CLOCK_GHZ), traffic=pmc["hbm_bytes"],
                             counters=pmc["source"],
                             valu_instructions_per_cast=pmc["SQ_INSTS_VALU"] / max(1, local["casts"]),
                             lanes_active=pmc.get("lanes_active"), l2_hit_rate=pmc.get("l2_hit_rate"),
