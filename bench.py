@@ -9,7 +9,8 @@ itself (before anything touches a GPU) and relays rank 0's line.  --gpus must eq
 
 A step is one frame of the scene after the camera-side set-up (scene, trees and — in the scene's
 default probe-gather mode — the probe pass and its keep-test index are resident in HBM before the
-timed region): sinks reset, emitter deposits (rank 0 only: they enter the sum once), the photon pass
+timed region; their device time is reported as `setup_ms`, and --step frame+probes puts them inside
+the step): sinks reset, emitter deposits (rank 0 only: they enter the sum once), the photon pass
 over this rank's share of the photon indices, the gather of this rank's deposits into its camera
 buffers, then one RCCL all-reduce(sum) per camera buffer and one of the counters when N > 1.
 Rank r of N traces photon indices [r*P/N, (r+1)*P/N) of every light; P is the scene's budget
@@ -175,8 +176,10 @@ def main():
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="strong: the scene's photon budget is split across the GPUs (the metric's workload); "
                          "weak: every GPU traces the scene's full budget (global budget = N x scene)")
-    ap.add_argument("--step", default="frame", choices=["frame", "pass"],
-                    help="frame: emitter deposits, photon pass, gather, all-reduce; pass: the photon pass and the all-reduce")
+    ap.add_argument("--step", default="frame", choices=["frame", "pass", "frame+probes"],
+                    help="frame: emitter deposits, photon pass, gather, all-reduce; pass: the photon pass and the all-reduce; "
+                         "frame+probes: the frame with its camera-side set-up inside the step as well (probe pass of every "
+                         "camera, probe index and store), which the reference's photonPassSeconds includes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--reuse-order", action="store_true",
                     help="steps after the first reuse the pass's emission order (the frames of a sequence: same ids, "
@@ -268,16 +271,36 @@ def main():
 
     first, count = parallel.shard_range(photons, rank, world)
     store_ranks = world if world > 1 else max(1, args.store_share)
-    if store_ranks > 1 and sink == "probe":
-        # the frame has ONE store: a rank keeps the emitter deposits (rank 0) plus 1/N of the rest
-        tracer.reset()
-        frame.share_store(tracer, setup["store_capacity"], max(gather_cell * 0.5, 1e-6), rank, store_ranks)
     sink_mode = {"none": rt.tracer.SINK_NONE, "probe": rt.tracer.SINK_PROBE, "splat": rt.tracer.SINK_SPLAT}[sink]
-    whole_frame = args.step == "frame"
+    whole_frame = args.step in ("frame", "frame+probes")
+    with_probes = args.step == "frame+probes" and sink == "probe"
+
+    def camera_side_setup():
+        """The frame's set-up as Renderer::renderFrame runs it, on the device: the probe pass of every gathering
+        camera, the keep-test index over the records and the store behind it (reference src/Renderer.cpp:297-419),
+        and this rank's share of the store when the frame is spread over ranks."""
+        tracer.forget_gather_points()
+        for c in gathering:
+            tracer.count_gather_points(c)
+        tracer.set_probes_from_cameras(setup["keep_radius"], setup["keep_radius"], 256, int(scene.settings.bounce_store_capacity))
+        if store_ranks > 1:
+            # the frame has ONE store: a rank keeps the emitter deposits (rank 0) plus 1/N of the rest
+            tracer.reset()
+            frame.share_store(tracer, setup["store_capacity"], max(gather_cell * 0.5, 1e-6), rank, store_ranks)
+
+    setup_ms = None
+    if sink == "probe":
+        camera_side_setup()
+        setup_ms = tracer.setup_timings()
 
     kernel_ms, sort_ms, gather_ms = [], [], []
 
     def step(timed):
+        if with_probes:
+            camera_side_setup()
+            if os.environ.get("RT_BENCH_VERBOSE"):
+                tracer.synchronize()
+                print(f"[bench] camera-side set-up done at {time.perf_counter():.4f}", file=sys.stderr)
         tracer.reset()
         if whole_frame and sink == "probe" and rank == 0:
             tracer.deposit_emitters(max(gather_cell * 0.5, 1e-6))
@@ -295,6 +318,8 @@ def main():
             for t in buffers:
                 dist.all_reduce(t)
         c = tracer.counters()  # synchronises the stream
+        if os.environ.get("RT_BENCH_VERBOSE"):
+            print(f"[bench] step done at {time.perf_counter():.4f}", file=sys.stderr)
         totals = torch.tensor([c[k] for k in COUNTER_NAMES], dtype=torch.int64, device=device)
         if collective:
             dist.all_reduce(totals)
@@ -386,7 +411,8 @@ def main():
                 "sink": sink,
                 "scene_sink": "probe" if scene.settings.use_probe_gather else "splat",
                 "emission_order": "reused from the step before" if args.reuse_order else "sorted anew every step",
-                "step": ("emitter deposits + photon pass + gather" if whole_frame and sink == "probe" else "photon pass")
+                "step": ("probe pass + probe index + " if with_probes else "")
+                        + ("emitter deposits + photon pass + gather" if whole_frame and sink == "probe" else "photon pass")
                         + (" + all-reduce" if collective else ""),
                 "bounce_threshold": int(scene.settings.bounce_threshold),
                 "meshes": "procedural stand-ins (reference OBJ files are Git-LFS pointers)",
@@ -398,6 +424,8 @@ def main():
             "casts_per_s": totals["casts"] / (ms_per_step * 1e-3),
             "stages_ms": {"sort": avg_sort_ms, "trace": 1e3 * avg_kernel_s,
                           "gather": (sum(gather_ms) / len(gather_ms)) if gather_ms else 0.0},
+            # device time of the camera-side set-up of a frame (outside the step unless --step frame+probes)
+            "setup_ms": setup_ms,
             "photon_pass_bounces_per_s": local["bounces"] * world / ((avg_sort_ms * 1e-3) + avg_kernel_s)
             if avg_kernel_s > 0 else None,
             "roofline": roofline,

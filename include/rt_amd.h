@@ -16,7 +16,9 @@
  *   - a handle is bound to one GPU and is not thread-safe; use one host thread (or
  *     one process) per GPU.
  *   - all kernels are launched on the handle's stream (rt_set_stream; default: the
- *     null stream); rt_trace is asynchronous, every rt_read_* synchronises first.
+ *     null stream); rt_trace returns once its last launch is queued — at once for a pass
+ *     below 4 Mi photons, after the launches of the earlier bounce levels have finished for
+ *     a larger one (see rt_trace) —, every rt_read_* synchronises first.
  *   - there is NO CPU fallback: without a usable GPU every call that computes fails
  *     with RT_ERR_DEVICE.
  */
@@ -208,6 +210,18 @@ int32_t rt_debug_device_memory(int32_t device, uint64_t* free_bytes, uint64_t* t
  * (RenderResult::photonPassSeconds, include/Renderer.h:51-103); the split is what a
  * per-kernel roofline needs.  Waits for the pass to finish. */
 int32_t rt_read_timings(rt_tracer* tracer, float* sort_ms, float* trace_ms);
+
+/* Device time of the frame's camera-side set-up, which the reference's photonPassSeconds includes
+ * (ProbeGather::collectGatherPoints and the ProbeIndex, reference src/Renderer.cpp:297-419): the probe pass
+ * of the cameras collected so far (rt_collect_gather_points / rt_set_probes_from_cameras), the build of
+ * the probe index by the last rt_set_probes* (cell keys, sort, table) and of its neighbour filter; 0 for
+ * what has not run, or ran on the host (index and filter of probes whose cells do not pack).  From HIP
+ * events on the tracer's stream; waits for the stream.  Any pointer may be NULL. */
+int32_t rt_read_setup_timings(rt_tracer* tracer, float* probe_pass_ms, float* index_build_ms, float* filter_build_ms);
+/* Forget the probe passes kept per camera (rt_collect_gather_points caches them): the next collect runs
+ * them again.  The reference runs them once per frame; a tracer serves one frame's scene, so this is
+ * for measuring a frame's set-up more than once. */
+int32_t rt_forget_gather_points(rt_tracer* tracer);
 
 /* The emission order the last rt_trace worked out (or reused): photon ids of the pass, numbered light
  * by light from 0, in the order the waves claim them.  The reference has no such list (its workers take

@@ -90,6 +90,15 @@ struct DeviceArray
             count = n;
         }
     }
+    // room for n elements at least: an allocation that is large enough already is kept (set-up that runs
+    // once per frame would otherwise hand gigabytes back to the driver and ask for them again)
+    void reserve(size_t n)
+    {
+        if (ptr == nullptr || count < n)
+        {
+            allocate(n);
+        }
+    }
     void upload(const std::vector<T>& host)
     {
         allocate(host.size());
@@ -198,6 +207,13 @@ struct rt_tracer
     std::vector<float*> boundBuffers;
 
     // sink A
+    struct ProbeBuildSpace  // work space of the probe index build
+    {
+        DeviceArray<double> points;
+        DeviceArray<unsigned long long> keysIn, keysOut, scalars, nearIn, nearOut;
+        DeviceArray<uint32_t> orderIn, orderOut, flag, bitsIn, bitsOut;
+        DeviceArray<unsigned char> scratch;
+    } probeBuildSpace;
     bool probesSet = false;
     uint64_t probeVersion = 0;  // bumped whenever the probes are set anew
     // The emitters' deposits of a frame depend on the probes, the patches and the spacing only: the
@@ -302,6 +318,14 @@ struct rt_tracer
         double indexedCellSize = 0.0;
     } gatherSpace;
     uint64_t storeVersion = 1;  // bumped by everything that writes the store or its cursor
+
+    // Device time of the frame's camera-side set-up, as pairs of events on the tracer's stream: [0] the probe
+    // pass of every camera, [1] the probe index (keys, sort, table), [2] its neighbour filter
+    struct TimedSpan
+    {
+        hipEvent_t begin = nullptr, end = nullptr;
+    };
+    std::vector<TimedSpan> setupSpans[3];
 
     rtd::SceneView view{};
     int computeUnits = 0;
@@ -1031,6 +1055,32 @@ uint64_t cellSlot(const CellKey& k, uint64_t mask)
     return ((h * 0x9E3779B97F4A7C15ull) >> 20) & mask;
 }
 
+// A span of device work of kind `kind` (rt_tracer::setupSpans) starts / ends here on the tracer's stream.
+size_t beginSetupSpan(rt_tracer* tracer, int kind)
+{
+    rt_tracer::TimedSpan span;
+    check(hipEventCreate(&span.begin), "hipEventCreate");
+    check(hipEventCreate(&span.end), "hipEventCreate");
+    check(hipEventRecord(span.begin, tracer->stream), "hipEventRecord");
+    tracer->setupSpans[kind].push_back(span);
+    return tracer->setupSpans[kind].size() - 1;
+}
+
+void endSetupSpan(rt_tracer* tracer, int kind, size_t index)
+{
+    check(hipEventRecord(tracer->setupSpans[kind][index].end, tracer->stream), "hipEventRecord");
+}
+
+void clearSetupSpans(rt_tracer* tracer, int kind)
+{
+    for (rt_tracer::TimedSpan& span : tracer->setupSpans[kind])
+    {
+        if (span.begin) (void)hipEventDestroy(span.begin);
+        if (span.end) (void)hipEventDestroy(span.end);
+    }
+    tracer->setupSpans[kind].clear();
+}
+
 // Runs the probe pass of one camera once and keeps its records on the device (for the
 // gather) and on the host (for rt_collect_gather_points).
 rt_tracer::GatherCache& ensureGatherPoints(rt_tracer* tracer, int32_t camera)
@@ -1046,14 +1096,15 @@ rt_tracer::GatherCache& ensureGatherPoints(rt_tracer* tracer, int32_t camera)
     const int64_t pixels = gw * gh;
     DeviceArray<unsigned long long> stats;
     cache.pixels = pixels;
-    cache.counts.allocate(static_cast<size_t>(pixels));
+    cache.counts.reserve(static_cast<size_t>(pixels));
     stats.allocate(3);
+    const size_t span = beginSetupSpan(tracer, 0);
     cache.counts.zero(tracer->stream);
     stats.zero(tracer->stream);
     rtd::launchGatherCount(tracer->view, camera, stride, pixels, cache.counts.ptr, stats.ptr, tracer->stream);
     check(hipGetLastError(), "gather count launch");
     // offsets of every pixel's records: exclusive scan of the counts, on the device
-    cache.offsets.allocate(static_cast<size_t>(pixels));
+    cache.offsets.reserve(static_cast<size_t>(pixels));
     size_t scanBytes = 0;
     check(rtd::scanCounts(nullptr, &scanBytes, cache.counts.ptr, cache.offsets.ptr, pixels, tracer->stream), "scan size query");
     DeviceArray<unsigned char> scanScratch;
@@ -1080,13 +1131,14 @@ rt_tracer::GatherCache& ensureGatherPoints(rt_tracer* tracer, int32_t camera)
     cache.total = total;
     cache.points.clear();
     cache.hostCopied = false;
-    cache.devicePoints.allocate(static_cast<size_t>(total));
+    cache.devicePoints.reserve(static_cast<size_t>(std::max<uint64_t>(total, 1)));
     if (total > 0)
     {
         rtd::launchGatherWrite(tracer->view, camera, stride, pixels, cache.counts.ptr, cache.offsets.ptr,
                                cache.devicePoints.ptr, tracer->stream);
         check(hipGetLastError(), "gather write launch");
     }
+    endSetupSpan(tracer, 0, span);
     for (int k = 0; k < 3; ++k)
     {
         cache.stats[k] = hostStats[k];
@@ -1125,17 +1177,22 @@ bool buildProbesOnDevice(rt_tracer* tracer, const double* probes, bool probesOnD
         return false;
     }
     hipStream_t stream = tracer->stream;
-    DeviceArray<double> points;
-    DeviceArray<unsigned long long> keysIn, keysOut, scalars;
-    DeviceArray<uint32_t> orderIn, orderOut, flag;
-    DeviceArray<unsigned char> scratch;
-    points.allocate(3 * n);
-    keysIn.allocate(n);
-    keysOut.allocate(n);
-    orderIn.allocate(n);
-    orderOut.allocate(n);
-    flag.allocate(1);
-    scalars.allocate(2);
+    clearSetupSpans(tracer, 1);
+    clearSetupSpans(tracer, 2);
+    const size_t indexSpan = beginSetupSpan(tracer, 1);
+    // work space kept between builds (a frame of a sequence builds the index of much the same probes again)
+    rt_tracer::ProbeBuildSpace& space = tracer->probeBuildSpace;
+    DeviceArray<double>& points = space.points;
+    DeviceArray<unsigned long long>&keysIn = space.keysIn, &keysOut = space.keysOut, &scalars = space.scalars;
+    DeviceArray<uint32_t>&orderIn = space.orderIn, &orderOut = space.orderOut, &flag = space.flag;
+    DeviceArray<unsigned char>& scratch = space.scratch;
+    points.reserve(3 * n);
+    keysIn.reserve(n);
+    keysOut.reserve(n);
+    orderIn.reserve(n);
+    orderOut.reserve(n);
+    flag.reserve(1);
+    scalars.reserve(2);
     flag.zero(stream);
     scalars.zero(stream);
     check(hipMemcpyAsync(points.ptr, probes, 3 * n * sizeof(double),
@@ -1152,7 +1209,7 @@ bool buildProbesOnDevice(rt_tracer* tracer, const double* probes, bool probesOnD
     }
     size_t bytes = 0;
     check(rtd::sortKeyPairs(nullptr, &bytes, keysIn.ptr, keysOut.ptr, orderIn.ptr, orderOut.ptr, n, stream), "sort size query");
-    scratch.allocate(std::max<size_t>(bytes, 1));
+    scratch.reserve(std::max<size_t>(bytes, 1));
     check(rtd::sortKeyPairs(scratch.ptr, &bytes, keysIn.ptr, keysOut.ptr, orderIn.ptr, orderOut.ptr, n, stream), "probe cell sort");
     rtd::launchCountRuns(keysOut.ptr, n, scalars.ptr, stream);
     unsigned long long cellCount = 0;
@@ -1164,24 +1221,26 @@ bool buildProbesOnDevice(rt_tracer* tracer, const double* probes, bool probesOnD
     {
         slots <<= 1;
     }
-    tracer->slotKey.allocate(3 * slots);
-    tracer->slotStart.allocate(slots);
-    tracer->slotCount.allocate(slots);
-    tracer->probePoints.allocate(3 * n + 2);  // ... and at a probe position
+    tracer->slotKey.reserve(3 * slots);
+    tracer->slotStart.reserve(slots);
+    tracer->slotCount.reserve(slots);
+    tracer->probePoints.reserve(3 * n + 2);  // ... and at a probe position
     tracer->slotCount.zero(stream);
-    tracer->packedCells.allocate(slots);
+    tracer->packedCells.reserve(slots);
     check(hipMemsetAsync(tracer->packedCells.ptr, 0xFF, slots * sizeof(rtd::PackedCell), stream), "hipMemsetAsync");
     rtd::launchProbeTable(keysOut.ptr, orderOut.ptr, points.ptr, n, tracer->slotKey.ptr, tracer->slotStart.ptr,
                           tracer->slotCount.ptr, tracer->packedCells.ptr, slots - 1, tracer->probePoints.ptr, stream);
 
+    endSetupSpan(tracer, 1, indexSpan);
+    const size_t filterSpan = beginSetupSpan(tracer, 2);
     // the 27-neighbour filter: candidate keys, sorted, runs merged
     const uint64_t candidates = 27 * cellCount;
-    DeviceArray<unsigned long long> nearIn, nearOut;
-    DeviceArray<uint32_t> bitsIn, bitsOut;
-    nearIn.allocate(candidates);
-    nearOut.allocate(candidates);
-    bitsIn.allocate(candidates);
-    bitsOut.allocate(candidates);
+    DeviceArray<unsigned long long>&nearIn = space.nearIn, &nearOut = space.nearOut;
+    DeviceArray<uint32_t>&bitsIn = space.bitsIn, &bitsOut = space.bitsOut;
+    nearIn.reserve(candidates);
+    nearOut.reserve(candidates);
+    bitsIn.reserve(candidates);
+    bitsOut.reserve(candidates);
     rtd::launchNeighbourKeys(keysOut.ptr, n, nearIn.ptr, bitsIn.ptr, scalars.ptr + 1, stream);
     bytes = 0;
     check(rtd::sortKeyPairs(nullptr, &bytes, nearIn.ptr, nearOut.ptr, bitsIn.ptr, bitsOut.ptr, candidates, stream),
@@ -1199,10 +1258,11 @@ bool buildProbesOnDevice(rt_tracer* tracer, const double* probes, bool probesOnD
     {
         nearSlots <<= 1;
     }
-    tracer->nearEntries.allocate(nearSlots + 2);  // the keep test reads 40 bytes at an entry
+    tracer->nearEntries.reserve(nearSlots + 2);  // the keep test reads 40 bytes at an entry
     check(hipMemsetAsync(tracer->nearEntries.ptr, 0xFF, nearSlots * sizeof(rtd::NearEntry), stream), "hipMemsetAsync");
     rtd::launchNeighbourTable(nearOut.ptr, bitsOut.ptr, candidates, tracer->nearEntries.ptr, nearSlots - 1, stream);
     check(hipGetLastError(), "probe grid build");
+    endSetupSpan(tracer, 2, filterSpan);
     check(hipStreamSynchronize(stream), "hipStreamSynchronize");
 
     rtd::ProbeView& pv = tracer->probeView;
@@ -1517,6 +1577,7 @@ void rt_destroy(rt_tracer* tracer)
         {
             if (e != nullptr) (void)hipEventDestroy(e);
         }
+        for (int kind = 0; kind < 3; ++kind) clearSetupSpans(tracer, kind);
 #ifdef RT_DIAG
         rtd::printDiagnostics();
 #endif
@@ -1579,8 +1640,8 @@ void setProbes(rt_tracer* tracer, const double* probes, bool probesOnDevice, uin
     // of the memory that is free; none when the budget cannot come near the capacity.
     const uint64_t room = overflowRoom(tracer, store_capacity);
     tracer->storeAllocated = store_capacity + room;
-    tracer->storeRecords.allocate(static_cast<size_t>(tracer->storeAllocated) * 13);
-    if (room > 0) tracer->storeKeys.allocate(static_cast<size_t>(tracer->storeAllocated) + 1);
+    tracer->storeRecords.reserve(static_cast<size_t>(tracer->storeAllocated) * 13);
+    if (room > 0) tracer->storeKeys.reserve(static_cast<size_t>(tracer->storeAllocated) + 1);
     else tracer->storeKeys.release();
     // the usual case (one cell of reach, coordinates that pack) is built on the device
     if (buildProbesOnDevice(tracer, probes, probesOnDevice, n, invCellSize, keepRadius))
@@ -2396,6 +2457,41 @@ int32_t rt_read_timings(rt_tracer* tracer, float* sort_ms, float* trace_ms)
         check(hipEventSynchronize(tracer->stageEvents[2]), "hipEventSynchronize");
         check(hipEventElapsedTime(sort_ms, tracer->stageEvents[0], tracer->stageEvents[1]), "hipEventElapsedTime");
         check(hipEventElapsedTime(trace_ms, tracer->stageEvents[1], tracer->stageEvents[2]), "hipEventElapsedTime");
+    });
+}
+
+int32_t rt_read_setup_timings(rt_tracer* tracer, float* probe_pass_ms, float* index_build_ms, float* filter_build_ms)
+{
+    return guarded([&]() {
+        require(tracer != nullptr, "tracer is null");
+        activate(tracer);
+        check(hipStreamSynchronize(tracer->stream), "hipStreamSynchronize");
+        float* out[3] = {probe_pass_ms, index_build_ms, filter_build_ms};
+        for (int kind = 0; kind < 3; ++kind)
+        {
+            float total = 0.0f;
+            for (const rt_tracer::TimedSpan& span : tracer->setupSpans[kind])
+            {
+                float ms = 0.0f;
+                check(hipEventElapsedTime(&ms, span.begin, span.end), "hipEventElapsedTime");
+                total += ms;
+            }
+            if (out[kind] != nullptr) *out[kind] = total;
+        }
+    });
+}
+
+int32_t rt_forget_gather_points(rt_tracer* tracer)
+{
+    return guarded([&]() {
+        require(tracer != nullptr, "tracer is null");
+        activate(tracer);
+        check(hipStreamSynchronize(tracer->stream), "hipStreamSynchronize");
+        for (auto& cache : tracer->gatherCache)
+        {
+            cache->valid = false;
+        }
+        clearSetupSpans(tracer, 0);
     });
 }
 

@@ -60,6 +60,8 @@ _SIGNATURES = {
     "rt_comm_init_all": (C.c_int32, [C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_void_p)]),
     "rt_comm_destroy": (C.c_int32, [C.c_void_p]),
     "rt_read_timings": (C.c_int32, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "rt_read_setup_timings": (C.c_int32, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "rt_forget_gather_points": (C.c_int32, [C.c_void_p]),
     "rt_read_emission_order": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
     "rt_read_counters": (C.c_int32, [C.c_void_p, C.POINTER(RtCounters)]),
     "rt_read_camera_buffer": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p]),
@@ -246,6 +248,16 @@ class Tracer:
         sort_ms, trace_ms = C.c_float(), C.c_float()
         _check(tracer_lib().rt_read_timings(self._handle, C.byref(sort_ms), C.byref(trace_ms)))
         return float(sort_ms.value), float(trace_ms.value)
+
+    def setup_timings(self):
+        """Device ms of the camera-side set-up so far: probe pass, probe index, neighbour filter."""
+        a, b, c = C.c_float(), C.c_float(), C.c_float()
+        _check(tracer_lib().rt_read_setup_timings(self._handle, C.byref(a), C.byref(b), C.byref(c)))
+        return {"probe_pass": float(a.value), "index_build": float(b.value), "filter_build": float(c.value)}
+
+    def forget_gather_points(self):
+        """The next collect / count of gather points runs the probe pass again."""
+        _check(tracer_lib().rt_forget_gather_points(self._handle))
 
     def emission_order(self):
         """Photon ids of the last pass (numbered light by light from 0) in the order they were traced;
