@@ -196,7 +196,7 @@ struct rt_tracer
     DeviceArray<unsigned char> cacheImage;
     DeviceArray<rtd::Node> nodes;
     DeviceArray<double> triRec, triNrm;
-    DeviceArray<int32_t> triId;
+    DeviceArray<int32_t> triId, triOwner;
     DeviceArray<rtd::Material> materials;
     DeviceArray<rtd::Light> lights;
     DeviceArray<rtd::Camera> cameras;
@@ -402,48 +402,43 @@ void buildScene(rt_tracer* t, const rt_scene* scene)
         double lo[3], hi[3];  // object-space bounds
     };
     std::vector<MeshSpan> spans;
+    std::vector<int32_t> triOwner;  // per slot: the volume a grouped triangle belongs to (-1: the volume that is cast)
     int maxDepth = 1;
-    for (int64_t m = 0; m < scene->mesh_count; ++m)
-    {
-        const rt_mesh& mesh = scene->meshes[m];
-        require(mesh.first_triangle >= 0 && mesh.triangle_count >= 0 &&
-                    mesh.first_triangle + mesh.triangle_count <= scene->triangle_count,
-                "mesh triangle range out of bounds");
-        require(mesh.triangle_count < (1ll << 26), "mesh too large");
-        const double* pos = scene->tri_pos + 9 * mesh.first_triangle;
-        const double* nrm = scene->tri_nrm + 9 * mesh.first_triangle;
+    const double pad = 4e-6 * sceneScale;
+    // One mesh as the device walks it: `count` triangles (pos / nrm: 9 doubles each) with the reference's
+    // tree over them (ranks and node boxes); ownerOf / idOf give, per triangle, the volume it reports and
+    // its index there (null: the volume that is cast, the triangle's own index).
+    auto addSpan = [&](const double* pos, const double* nrm, int64_t count, const rtbvh::FlatMesh& reference,
+                       const int32_t* ownerOf, const int32_t* idOf, const char* label, long long number) {
         // the reference's tree gives every triangle its visiting rank and node box; the tree the
         // device walks is built over the same triangles.  Its boxes are tested in single precision
         // against ray origins anywhere in the scene: padding of a few millionths of the scene's
         // scale is an order of magnitude above what that loses (6e-8 of the origin's size in the
         // origin, 2e-7 of a plane's distance in the products), and costs no traversal steps.
         double extent = 0.0;
-        for (int64_t i = 0; i < 9 * mesh.triangle_count; ++i)
+        for (int64_t i = 0; i < 9 * count; ++i)
         {
             extent = std::max(extent, std::fabs(pos[i]));
         }
-        const double pad = 4e-6 * sceneScale;
-        const rtbvh::FlatMesh flat =
-            rtbvh::buildSurfaceArea(pos, mesh.triangle_count, rtbvh::build(pos, mesh.triangle_count), pad, leafSize);
+        const rtbvh::FlatMesh flat = rtbvh::buildSurfaceArea(pos, count, reference, pad, leafSize);
         const rtbvh::WideMesh wide = rtbvh::breadthFirst(rtbvh::widen(flat));
         maxDepth = std::max(maxDepth, wide.pushDepth);
         if (std::getenv("RT_AMD_VERBOSE"))
         {
-            std::fprintf(stderr, "[rt_amd] mesh %lld: %lld triangles, %zu inner nodes, %d levels of them\n",
-                         static_cast<long long>(m), static_cast<long long>(mesh.triangle_count), wide.nodes.size(),
-                         wide.pushDepth);
+            std::fprintf(stderr, "[rt_amd] %s %lld: %lld triangles, %zu inner nodes, %d levels of them\n", label, number,
+                         static_cast<long long>(count), wide.nodes.size(), wide.pushDepth);
         }
         MeshSpan span;
         span.nodeBase = static_cast<int32_t>(nodes.size());
         span.nodeCount = static_cast<int32_t>(wide.nodes.size());
         span.triBase = static_cast<int64_t>(triId.size());
-        span.triCount = mesh.triangle_count;
+        span.triCount = count;
         span.extent = extent;
         for (int k = 0; k < 3; ++k)
         {
-            span.lo[k] = span.hi[k] = mesh.triangle_count > 0 ? pos[k] : 0.0;
+            span.lo[k] = span.hi[k] = count > 0 ? pos[k] : 0.0;
         }
-        for (int64_t i = 0; i < 3 * mesh.triangle_count; ++i)
+        for (int64_t i = 0; i < 3 * count; ++i)
         {
             for (int k = 0; k < 3; ++k)
             {
@@ -491,9 +486,127 @@ void buildScene(rt_tracer* t, const rt_scene* scene)
             triRec.push_back(wordAsDouble);
             triRec.insert(triRec.end(), flat.referenceBox.begin() + 6 * slot, flat.referenceBox.begin() + 6 * slot + 6);
             triNrm.insert(triNrm.end(), nrm + 9 * original, nrm + 9 * original + 9);
-            triId.push_back(original);
+            triId.push_back(idOf ? idOf[original] : original);
+            triOwner.push_back(ownerOf ? ownerOf[original] : -1);
         }
         spans.push_back(span);
+    };
+    for (int64_t m = 0; m < scene->mesh_count; ++m)
+    {
+        const rt_mesh& mesh = scene->meshes[m];
+        require(mesh.first_triangle >= 0 && mesh.triangle_count >= 0 &&
+                    mesh.first_triangle + mesh.triangle_count <= scene->triangle_count,
+                "mesh triangle range out of bounds");
+        require(mesh.triangle_count < (1ll << 26), "mesh too large");
+        const double* pos = scene->tri_pos + 9 * mesh.first_triangle;
+        const double* nrm = scene->tri_nrm + 9 * mesh.first_triangle;
+        addSpan(pos, nrm, mesh.triangle_count, rtbvh::build(pos, mesh.triangle_count), nullptr, nullptr, "mesh", static_cast<long long>(m));
+    }
+
+    // ---- flat meshes of one pose, cast together ----
+    // A room's walls are five meshes of two triangles in one pose.  Cast one by one (as the reference's loop
+    // over the volumes does, src/Worker.cpp:539-567), each costs every wave a box test, a walk and two triangle
+    // tests for the few lanes whose ray goes its way.  Static mesh volumes that share a pose and whose
+    // triangles all lie in one plane are therefore ALSO put into one tree, which is cast once in their stead:
+    // a ray meets a plane once, so such a volume's closest hit is its only hit, and "per volume the closest hit,
+    // dropped when it is not beyond the self-hit floor, then the nearest of the volumes, the first of them on
+    // a tie" is "the nearest hit beyond the floor over all their triangles, on a tie the first volume's, then
+    // the first in that volume's visiting order" — which is how the joint tree ranks its triangles.  (Two
+    // triangles of one volume that overlap at the hit point give two hits of the same point; should their
+    // distances straddle the floor by a rounding error the reference drops the volume and the joint cast keeps
+    // the farther one.  The floor is 1e-4 and a distance would have to equal it to the last bit.)
+    struct Group
+    {
+        std::vector<int64_t> members;  // volume indices, ascending
+        size_t span = 0;
+    };
+    std::vector<Group> groups;
+    std::vector<int32_t> groupOf(static_cast<size_t>(std::max<int64_t>(0, scene->volume_count)), -1);
+    {
+        const char* wanted = std::getenv("RT_AMD_GROUP_FLAT_MESHES");
+        const bool enabled = wanted == nullptr || std::atoi(wanted) != 0;
+        auto flat = [&](const rt_mesh& mesh) {
+            // every vertex in the plane of the first triangle that has an area, exactly (axis-parallel walls are;
+            // anything else may fail by a rounding error and is then simply cast on its own)
+            const double* pos = scene->tri_pos + 9 * mesh.first_triangle;
+            for (int64_t t = 0; t < mesh.triangle_count; ++t)
+            {
+                const double* p = pos + 9 * t;
+                const double e1[3] = {p[3] - p[0], p[4] - p[1], p[5] - p[2]}, e2[3] = {p[6] - p[0], p[7] - p[1], p[8] - p[2]};
+                const double n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+                if (n[0] == 0.0 && n[1] == 0.0 && n[2] == 0.0) continue;
+                for (int64_t i = 0; i < 3 * mesh.triangle_count; ++i)
+                {
+                    const double* v = pos + 3 * i;
+                    if ((v[0] - p[0]) * n[0] + (v[1] - p[1]) * n[1] + (v[2] - p[2]) * n[2] != 0.0) return false;
+                }
+                return true;
+            }
+            return false;  // no triangle with an area
+        };
+        for (int64_t i = 0; enabled && i < scene->volume_count; ++i)
+        {
+            const rt_volume& rv = scene->volumes[i];
+            if (rv.type != RT_VOLUME_MESH || rv.animation != 0 || rv.mesh < 0 || rv.mesh >= scene->mesh_count) continue;
+            const rt_mesh& mesh = scene->meshes[rv.mesh];
+            if (mesh.triangle_count <= 0 || mesh.triangle_count > 4096 || !flat(mesh)) continue;
+            int32_t found = -1;
+            for (size_t g = 0; g < groups.size() && found < 0; ++g)
+            {
+                const rt_volume& first = scene->volumes[groups[g].members.front()];
+                if (std::memcmp(first.position, rv.position, sizeof(rv.position)) == 0 &&
+                    std::memcmp(first.rotation, rv.rotation, sizeof(rv.rotation)) == 0)
+                {
+                    found = static_cast<int32_t>(g);
+                }
+            }
+            if (found < 0)
+            {
+                groups.push_back(Group{});
+                found = static_cast<int32_t>(groups.size() - 1);
+            }
+            groups[static_cast<size_t>(found)].members.push_back(i);
+            groupOf[static_cast<size_t>(i)] = found;
+        }
+        for (size_t g = 0; g < groups.size(); ++g)
+        {
+            Group& group = groups[g];
+            if (group.members.size() < 2)
+            {
+                for (int64_t member : group.members) groupOf[static_cast<size_t>(member)] = -1;
+                group.members.clear();
+                continue;
+            }
+            // the members' triangles one after the other, and the reference's trees likewise: a triangle's
+            // rank is its member's place in the group, then its rank in that member's own tree
+            std::vector<double> pos, nrm;
+            std::vector<int32_t> ownerOf, idOf;
+            rtbvh::FlatMesh reference;
+            for (int64_t member : group.members)
+            {
+                const rt_mesh& mesh = scene->meshes[scene->volumes[member].mesh];
+                const double* mpos = scene->tri_pos + 9 * mesh.first_triangle;
+                const double* mnrm = scene->tri_nrm + 9 * mesh.first_triangle;
+                const int32_t base = static_cast<int32_t>(idOf.size());
+                const rtbvh::FlatMesh own = rtbvh::build(mpos, mesh.triangle_count);
+                for (rtbvh::FlatNode node : own.nodes)
+                {
+                    node.triStart += base;
+                    reference.nodes.push_back(node);
+                }
+                for (int32_t original : own.order) reference.order.push_back(base + original);
+                pos.insert(pos.end(), mpos, mpos + 9 * mesh.triangle_count);
+                nrm.insert(nrm.end(), mnrm, mnrm + 9 * mesh.triangle_count);
+                for (int64_t t = 0; t < mesh.triangle_count; ++t)
+                {
+                    ownerOf.push_back(static_cast<int32_t>(member));
+                    idOf.push_back(static_cast<int32_t>(t));
+                }
+            }
+            group.span = spans.size();
+            addSpan(pos.data(), nrm.data(), static_cast<int64_t>(idOf.size()), reference, ownerOf.data(), idOf.data(), "group of flat meshes",
+                    static_cast<long long>(g));
+        }
     }
 
     // ---- the scene cache of the trace kernel: what goes into LDS behind the traversal stacks ----
@@ -579,16 +692,22 @@ void buildScene(rt_tracer* t, const rt_scene* scene)
         std::memcpy(v.param, rv.param, sizeof(v.param));
         require(rv.animation >= 0 && rv.animation <= scene->animation_count, "volume animation index out of range");
         v.animation = rv.animation - 1;  // the description counts from 1, 0 meaning static
+        // the first member of a group of flat meshes is cast for all of them, the others are passed over
+        const int32_t groupIndex = groupOf[static_cast<size_t>(i)];
+        const bool leads = groupIndex >= 0 && groups[static_cast<size_t>(groupIndex)].members.front() == i;
+        const MeshSpan* castSpan = nullptr;
         if (rv.type == RT_VOLUME_MESH)
         {
             require(rv.mesh >= 0 && rv.mesh < scene->mesh_count, "volume mesh index out of range");
-            v.nodeBase = spans[rv.mesh].nodeBase;
-            v.nodeCount = spans[rv.mesh].nodeCount;
-            v.triBase = spans[rv.mesh].triBase;
-            v.extent = spans[rv.mesh].extent;
-            v.ldsNodeCount = spans[rv.mesh].ldsNodeCount;
-            v.ldsNodeOffset = spans[rv.mesh].ldsNodeOffset;
-            v.ldsTriOffset = spans[rv.mesh].ldsTriOffset;
+            castSpan = &spans[groupIndex >= 0 ? groups[static_cast<size_t>(groupIndex)].span : static_cast<size_t>(rv.mesh)];
+            v.nodeBase = castSpan->nodeBase;
+            v.nodeCount = castSpan->nodeCount;
+            v.triBase = castSpan->triBase;
+            v.extent = castSpan->extent;
+            v.ldsNodeCount = castSpan->ldsNodeCount;
+            v.ldsNodeOffset = castSpan->ldsNodeOffset;
+            v.ldsTriOffset = castSpan->ldsTriOffset;
+            if (groupIndex >= 0) v.type = leads ? rtd::kVolumeMeshGroup : rtd::kVolumePassedOver;
         }
         else
         {
@@ -618,7 +737,7 @@ void buildScene(rt_tracer* t, const rt_scene* scene)
         {
             if (rv.type == RT_VOLUME_MESH && scene->meshes[rv.mesh].triangle_count > 0)
             {
-                const MeshSpan& span = spans[rv.mesh];
+                const MeshSpan& span = *castSpan;
                 for (int c = 0; c < 8; ++c)
                 {
                     corners.push_back({(c & 1) ? span.hi[0] : span.lo[0], (c & 2) ? span.hi[1] : span.lo[1],
@@ -871,6 +990,7 @@ void buildScene(rt_tracer* t, const rt_scene* scene)
     t->triRec.upload(triRec);
     t->triNrm.upload(triNrm);
     t->triId.upload(triId);
+    t->triOwner.upload(triOwner);
     t->materials.upload(materials);
     t->lights.upload(lights);
     t->cameras.upload(t->cameraHost);
@@ -883,10 +1003,13 @@ void buildScene(rt_tracer* t, const rt_scene* scene)
     view.triRec = t->triRec.ptr;
     view.triNrm = t->triNrm.ptr;
     view.triId = t->triId.ptr;
+    view.triOwner = t->triOwner.ptr;
     view.materials = t->materials.ptr;
     view.lights = t->lights.ptr;
     view.cameras = t->cameras.ptr;
     view.volumeCount = static_cast<int32_t>(volumes.size());
+    view.groupCount = 0;
+    for (const Group& group : groups) view.groupCount += group.members.empty() ? 0 : 1;
     view.lightCount = static_cast<int32_t>(lights.size());
     view.cameraCount = static_cast<int32_t>(t->cameraHost.size());
     view.materialCount = static_cast<int32_t>(materials.size());

@@ -157,6 +157,11 @@ struct Node
 static_assert(sizeof(Node) == 64, "Node must be one 64-byte line");
 constexpr int32_t kNoChild = static_cast<int32_t>(0x80000000u);
 
+// Volume::type beyond the scene description's RT_VOLUME_*: the first of several flat meshes of one pose,
+// which is cast for all of them through a tree over all their triangles (SceneView::triOwner tells
+// whose triangle was hit), and the others of them, which the loop over the volumes passes over.
+constexpr int32_t kVolumeMeshGroup = 16, kVolumePassedOver = 17;
+
 struct Volume
 {
     int32_t type, material, nodeBase, nodeCount;
@@ -242,6 +247,7 @@ struct SceneView
     const double* triRec;
     const double* triNrm;  // [9 * T] page order
     const int32_t* triId;  // slot -> index within the mesh (load order)
+    const int32_t* triOwner;  // slot -> the volume the triangle belongs to, for the trees of kVolumeMeshGroup (else -1)
     const Material* materials;
     const Light* lights;
     Camera* cameras;
@@ -250,6 +256,7 @@ struct SceneView
     int32_t stackDepth;  // traversal stack entries per lane (inner levels of the deepest tree)
     int32_t volumeCount, lightCount, cameraCount, bounceThreshold;
     int32_t materialCount, meshVolumeCount;
+    int32_t groupCount;  // volumes of kVolumeMeshGroup
     double terminationThreshold;
     double splatLuminanceClamp;
     uint64_t photonsPerLight;
@@ -711,7 +718,7 @@ RT_DEV bool slabTestChild(const RayPrepSingle& q, const float* box, float* entry
 // Cached: the kernel holds the top of the tree (ldsNodeCount nodes at ldsNodes) and possibly the
 // mesh's triangles (ldsTris, 10 doubles each; null: none) in LDS.
 template <bool Cached>
-RT_DEV bool castMesh(const SceneView& s, int32_t nodeBase, int32_t nodeCount, int64_t triBase, double extent,
+RT_DEV bool castMesh(const SceneView& s, int32_t nodeBase, int32_t nodeCount, int64_t triBase, double extent, double floor,
                      const Ray& ray, const RayPrep& prep, const TraversalStack& stack, double bound, double* bary,
                      Vec* position, double* distance, int32_t* triSlot, int32_t ldsNodeCount = 0,
                      const unsigned char* ldsNodes = nullptr, const double* ldsTris = nullptr)
@@ -856,7 +863,9 @@ RT_DEV bool castMesh(const SceneView& s, int32_t nodeBase, int32_t nodeCount, in
                 word = reinterpret_cast<const unsigned long long*>(rec)[9];
                 hitsTriangle = rayIntersectsTriangle(ray, prep, rec, b3, &pos, &d);
             }
-            if (hitsTriangle)
+            // (floor: the tree of several flat volumes takes no hit at or below the self-hit floor, which
+            // drops such a volume's only hit as the caller would; every other tree passes -1, no distance is)
+            if (hitsTriangle && d > floor)
             {
                 const int32_t rank = static_cast<int32_t>(static_cast<uint32_t>(word));
                 bool wins = !found || d < best || (d == best && rank < bestRank);
@@ -1012,6 +1021,16 @@ RT_DEV Quat quatInverse(const Quat& q)  // reference src/Quaternion.cpp:39-52
     return Quat{-q.x * scale, -q.y * scale, -q.z * scale, q.w * scale};
 }
 
+// The reference keeps a volume's hit when it is strictly nearer than the nearest so far, and visits the
+// volumes in their order: of equally distant hits the first volume's stays.  Flat meshes of one pose are
+// cast together at the place of the first of them, so the order of the visits is no longer the order of the
+// volumes and the tie is settled by the volumes' numbers instead.
+// (`groups`: the scene has such casts; without them the visits are in the volumes' order, as the reference's)
+RT_DEV bool closer(bool groups, double dist, int32_t volume, double nearest, int32_t nearestVolume)
+{
+    return dist < nearest || (groups && dist == nearest && volume < nearestVolume);
+}
+
 // Nearest valid hit over all volumes: Volume::castRayAt for each volume in object
 // order (src/Volume.cpp:34-81), then the strict-minimum selection with the self-hit
 // floor applied AFTER each volume's own closest hit was chosen
@@ -1019,7 +1038,9 @@ RT_DEV Quat quatInverse(const Quat& q)  // reference src/Quaternion.cpp:39-52
 // produced (occlusion test, src/Worker.cpp:314-333).  With Animated set, a keyframed
 // volume is posed at `time` (the photon's or the camera sample's) for the cast; without
 // it every volume keeps its scene-load transform and `time` is unused.
-template <bool Animated, bool Cached = false>
+// Grouped: the scene may hold casts of several flat meshes at once (kVolumeMeshGroup); a kernel that is
+// only launched for scenes without them passes false and carries none of their handling.
+template <bool Animated, bool Cached = false, bool Grouped = true>
 RT_DEV bool castScene(const SceneView& s, const Ray& ray, float time, double selfHit, bool needSurface, Hit* out)
 {
     const TraversalStack stack = laneStack();
@@ -1039,6 +1060,11 @@ RT_DEV bool castScene(const SceneView& s, const Ray& ray, float time, double sel
         RT_DIAG_TIC(boxStart);
         const auto vol = uniformRead(s.volumes + v);  // v is the same in every lane
         const int32_t type = vol->type;
+        if (Grouped && type == kVolumePassedOver)
+        {
+            continue;  // cast with the first flat mesh of its pose
+        }
+        const bool group = Grouped && type == kVolumeMeshGroup;
         if (vol->hasWorldBox)
         {
             float box[6], entry;
@@ -1083,8 +1109,8 @@ RT_DEV bool castScene(const SceneView& s, const Ray& ray, float time, double sel
         Vec pos, nrm = mk(0, 0, 0);
         double dist;
         bool found = false;
-        int32_t tri = -1;
-        if (type == RT_VOLUME_MESH)
+        int32_t tri = -1, hitVolume = v;
+        if (type == RT_VOLUME_MESH || group)
         {
             if (!prepared)
             {
@@ -1099,17 +1125,21 @@ RT_DEV bool castScene(const SceneView& s, const Ray& ray, float time, double sel
             {
                 const unsigned char* cache = sceneCache(s);
                 const int32_t triOffset = vol->ldsTriOffset;
-                found = castMesh<true>(s, vol->nodeBase, vol->nodeCount, triBase, vol->extent, local, prep, stack, minDistance,
+                found = castMesh<true>(s, vol->nodeBase, vol->nodeCount, triBase, vol->extent, group ? selfHit : -1.0, local, prep, stack, minDistance,
                                        bary, &pos, &dist, &slot, vol->ldsNodeCount, cache + vol->ldsNodeOffset,
                                        triOffset >= 0 ? reinterpret_cast<const double*>(cache + triOffset) : nullptr);
             }
             else
             {
-                found = castMesh<false>(s, vol->nodeBase, vol->nodeCount, triBase, vol->extent, local, prep, stack, minDistance,
+                found = castMesh<false>(s, vol->nodeBase, vol->nodeCount, triBase, vol->extent, group ? selfHit : -1.0, local, prep, stack, minDistance,
                                         bary, &pos, &dist, &slot);
             }
             RT_DIAG_TIC(normalStart);
-            if (found && dist < minDistance && dist > selfHit)
+            if (group && found)
+            {
+                hitVolume = s.triOwner[triBase + slot];
+            }
+            if (found && closer(Grouped && s.groupCount > 0, dist, hitVolume, minDistance, bestVolume) && dist > selfHit)
             {
                 if (needSurface)
                 {
@@ -1144,13 +1174,13 @@ RT_DEV bool castScene(const SceneView& s, const Ray& ray, float time, double sel
             found = rayIntersectsPlane(local, mk(vol->param[0], vol->param[1], vol->param[2]), vol->param[3], &pos, &nrm,
                                        &dist);
         }
-        if (found && dist < minDistance && dist > selfHit)
+        if (found && closer(Grouped && s.groupCount > 0, dist, hitVolume, minDistance, bestVolume) && dist > selfHit)
         {
             valid = true;
             minDistance = dist;
             bestPos = pos;
             bestNrm = nrm;
-            bestVolume = v;
+            bestVolume = hitVolume;
             bestTri = tri;
         }
     }

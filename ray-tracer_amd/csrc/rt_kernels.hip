@@ -495,7 +495,7 @@ RT_DEV void addToPixels(float* buffer, bool emit, uint32_t index, const Color& c
 // (src/Utility.cpp:43-50) and Buffer::addColor (src/Buffer.cpp:22-37).  Every lane that is active at
 // the call goes through every camera (the pixel sums are formed across the wave); `splats` is false
 // for a lane whose hit deposits nothing (a delta surface).
-template <bool Animated>
+template <bool Animated, bool Grouped>
 RT_DEV void splatToCamera(const TraceArgs& a, bool splats, const Vec& incoming, const Color& photonColor, int bounces,
                           int lightId, float time, const Hit& hit, const Material& material, const WaveTally& lc)
 {
@@ -549,7 +549,7 @@ RT_DEV void splatToCamera(const TraceArgs& a, bool splats, const Vec& incoming, 
                 shadow.o = hit.position;
                 shadow.d = toCameraDir;
                 Hit occluder;
-                if (castScene<Animated, true>(s, shadow, time, kSelfHitThreshold, false, &occluder) &&
+                if (castScene<Animated, true, Grouped>(s, shadow, time, kSelfHitThreshold, false, &occluder) &&
                     occluder.distance < cameraDistance)
                 {
                     break;
@@ -663,7 +663,9 @@ RT_DEV uint32_t rayKey(const TraceArgs& a, const Ray& ray)
 
 // Sink selects the deposit path and Record the per-photon path dump at compile time, so
 // that the probe-sink kernel carries neither the splat's shadow-ray cast nor the dump.
-template <int Sink, bool Record, bool Animated>
+// Grouped: for scenes that cast several flat meshes of one pose at once (castScene); the kernels of the
+// scenes without such casts are compiled without their handling.
+template <int Sink, bool Record, bool Animated, bool Grouped>
 __global__ __launch_bounds__(kTraceThreads) __attribute__((amdgpu_waves_per_eu((Animated && !Record) ? 2 : 1))) void traceKernel(const TraceArgs a)
 {
     const SceneView& s = a.scene;
@@ -831,7 +833,7 @@ __global__ __launch_bounds__(kTraceThreads) __attribute__((amdgpu_waves_per_eu((
                 casts += 1;
                 tally(lc, kTallyCasts);
                 RT_DIAG_TIC(castStart);
-                const bool hitSomething = castScene<Animated, true>(s, ray, time, kSelfHitThreshold, true, &hit);
+                const bool hitSomething = castScene<Animated, true, Grouped>(s, ray, time, kSelfHitThreshold, true, &hit);
                 RT_DIAG_TOC(castStart, 1);
                 if (!hitSomething)
                 {
@@ -887,7 +889,7 @@ __global__ __launch_bounds__(kTraceThreads) __attribute__((amdgpu_waves_per_eu((
                         tally(lc, kTallyDensityDeposits);
                         densityAdd(a.density, hit.position, color, lc);
                     }
-                    splatToCamera<Animated>(a, !delta, ray.d, color, bounces, lightId, time, hit, material, lc);
+                    splatToCamera<Animated, Grouped>(a, !delta, ray.d, color, bounces, lightId, time, hit, material, lc);
                 }
 
                 RT_DIAG_TOC(depositStart, 5);
@@ -2579,14 +2581,19 @@ TraceKernel traceVariant(const TraceArgs& args)
 {
     const bool record = args.records.recordPhotons > 0;
     const bool animated = args.scene.animationCount > 0;
-    const int variant = (record ? 1 : 0) | (animated ? 2 : 0);
+    const bool grouped = args.scene.groupCount > 0;
+    const int variant = (record ? 1 : 0) | (animated ? 2 : 0) | (grouped ? 4 : 0);
 #define RT_TRACE_VARIANTS(sink)                                                  \
     switch (variant)                                                             \
     {                                                                            \
-    case 0: return traceKernel<sink, false, false>;                              \
-    case 1: return traceKernel<sink, true, false>;                               \
-    case 2: return traceKernel<sink, false, true>;                               \
-    default: return traceKernel<sink, true, true>;                               \
+    case 0: return traceKernel<sink, false, false, false>;                       \
+    case 1: return traceKernel<sink, true, false, false>;                        \
+    case 2: return traceKernel<sink, false, true, false>;                        \
+    case 3: return traceKernel<sink, true, true, false>;                         \
+    case 4: return traceKernel<sink, false, false, true>;                        \
+    case 5: return traceKernel<sink, true, false, true>;                         \
+    case 6: return traceKernel<sink, false, true, true>;                         \
+    default: return traceKernel<sink, true, true, true>;                         \
     }
     switch (args.sinkMode)
     {

@@ -84,4 +84,4 @@ def test_trace_kernels_keep_two_waves_per_simd():
             assert fields["Occupancy [waves/SIMD]"] == "2", (name, fields)
         assert fields["ScratchSize [bytes/lane]"] == "0", (name, fields)
         assert fields["VGPRs Spill"] == "0", (name, fields)
-    assert seen == 12
+    assert seen == 24
