@@ -128,6 +128,51 @@ def test_closest_hit_with_keyframed_volumes(rt, scene_opener):
     assert not np.array_equal(seen[0], seen[1]) and not np.array_equal(seen[1], seen[2])
 
 
+@pytest.mark.parametrize("name", ["scenes/CornellBoxGlassMirrorDiffuse.json", "scenes/MirrorKnot4k.json",
+                                  "scenes/CornellBox.json"])
+def test_closest_hit_where_flat_meshes_meet(rt, scene_opener, name, monkeypatch):
+    """A room's walls are flat meshes of one pose: the device casts them together through one tree over all
+    their triangles, where the reference casts volume after volume and keeps the first of equally distant
+    hits (reference src/Worker.cpp:539-567).  The cases that could tell the two apart are rays aimed exactly
+    at the lines and corners where walls meet (two volumes hit at one point), rays that start ON a wall (the
+    wall's own hit lies below the self-hit floor and the wall must then contribute nothing) and both floors
+    in use (1e-4 of the photon pass, epsilon of the probe pass).  Hits, distances and volume / triangle /
+    material ids equal the oracle's bit for bit, and equal those of a tracer that casts every wall on its own
+    (RT_AMD_GROUP_FLAT_MESHES=0)."""
+    entry = {"scene": name, "photons_per_light": 1000}
+    scene, tracer, orc = _open(rt, scene_opener, entry)
+    rng = np.random.default_rng(5)
+    lo, hi = np.array([-150.0, 0.0, -150.0]), np.array([150.0, 300.0, 150.0])  # the room of the Cornell scenes
+    n = 4000
+    inside = lo + (hi - lo) * rng.uniform(0.05, 0.95, size=(n, 3))
+    # targets on the room's edges and corners: every coordinate at a wall or a round number in between
+    grid = np.stack([rng.choice([-150.0, 150.0, -75.0, 0.0, 37.5], size=n), rng.choice([0.0, 300.0, 150.0, 62.5], size=n),
+                     rng.choice([150.0, -150.0, 0.0, 25.0], size=n)], axis=1)
+    rays = [np.concatenate([inside, grid - inside], axis=1)]
+    # rays that start on a wall, leaving it, grazing along it, and heading back into it
+    on_wall = inside.copy()
+    axis = rng.integers(0, 3, size=n)
+    side = rng.integers(0, 2, size=n)
+    on_wall[np.arange(n), axis] = np.where(side == 1, hi[axis], lo[axis])
+    directions = rng.normal(size=(n, 3))
+    directions[: n // 4, :] = 0.0
+    directions[np.arange(n // 4), (axis[: n // 4] + 1) % 3] = 1.0  # along the wall
+    rays.append(np.concatenate([on_wall, directions], axis=1))
+    rays = np.concatenate(rays, axis=0)
+    for floor in (1e-4, 2.220446049250313e-16):
+        got_f, got_i = tracer.cast_rays(rays, floor)
+        o_f, o_i = orc.cast_rays(rays, floor)
+        assert (got_i[:, 0] == 1).sum() > n
+        assert_bits_equal(got_f, o_f, f"hits at floor {floor}")
+        assert np.array_equal(got_i, o_i), f"ids at floor {floor}"
+    monkeypatch.setenv("RT_AMD_GROUP_FLAT_MESHES", "0")
+    apart = rt.Tracer(scene)
+    a_f, a_i = apart.cast_rays(rays)
+    t_f, t_i = tracer.cast_rays(rays)
+    assert_bits_equal(t_f, a_f, "walls cast together and apart")
+    assert np.array_equal(t_i, a_i)
+
+
 SCENES = {
     "furnace": {"scene": "tests/scenes/furnace.json", "photons_per_light": 4000},
     "mixed": {"scene": "tests/scenes/mixed.json", "photons_per_light": 1500},
