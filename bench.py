@@ -329,6 +329,11 @@ def main():
             kernel_ms.append(t_ms)
         return dict(zip(COUNTER_NAMES, [int(v) for v in totals.tolist()]))
 
+    # RT_BENCH_FAIL_RANK=<rank>: that rank dies before its first step (a test switch: the job must end with a
+    # failure promptly, not wait for the dead rank in a collective)
+    if os.environ.get("RT_BENCH_FAIL_RANK") is not None and int(os.environ["RT_BENCH_FAIL_RANK"]) == rank:
+        raise SystemExit(f"rank {rank}: injected failure (RT_BENCH_FAIL_RANK)")
+
     def fence():
         torch.cuda.synchronize(device)
         if collective:

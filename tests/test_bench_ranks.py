@@ -65,6 +65,30 @@ def test_one_rank_over_rccl():
         assert rccl["counters"][key] == plain["counters"][key], key
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("launcher", [True, False])
+def test_a_rank_that_dies_ends_the_job_with_a_failure(launcher):
+    """One rank of two exits before its first step: the job (under torch.distributed.run, or started by
+    bench.py itself) ends with a non-zero status within the time-out instead of waiting in a collective for the
+    rank that is gone, and prints no result line."""
+    import time
+    common = ["bench.py", "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--photons", "200000",
+              "--backend", "gloo", "--share-device"]
+    if launcher:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", "29547"] + common
+    else:
+        cmd = [sys.executable] + common
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", RT_BENCH_FAIL_RANK="1")
+    started = time.monotonic()
+    r = subprocess.run(cmd, cwd=REPO, capture_output=True, text=True, timeout=240, env=env)
+    assert r.returncode != 0
+    assert time.monotonic() - started < 200
+    assert not [line for line in r.stdout.splitlines() if line.startswith("{")]
+    assert "injected failure" in r.stdout + r.stderr
+
+
 def test_gpus_must_match_the_world_size():
     """A rank count that contradicts the launcher's is an error, on any machine (no GPU is touched)."""
     env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
