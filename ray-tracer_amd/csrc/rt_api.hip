@@ -210,9 +210,10 @@ struct rt_tracer
     struct ProbeBuildSpace  // work space of the probe index build
     {
         DeviceArray<double> points;
-        DeviceArray<unsigned long long> keysIn, keysOut, scalars, nearIn, nearOut;
-        DeviceArray<uint32_t> orderIn, orderOut, flag, bitsIn, bitsOut;
-        DeviceArray<unsigned char> scratch;
+        DeviceArray<unsigned long long> keysIn, keysOut, scalars, groupKey, listKeys[2];
+        DeviceArray<uint64_t> cellOrdinal, groupOrdinal;
+        DeviceArray<uint32_t> orderIn, orderOut, flag, heads, groupOwn, groupFirst, listEntries[2];
+        DeviceArray<unsigned char> scratch, mergeScratch;
     } probeBuildSpace;
     bool probesSet = false;
     uint64_t probeVersion = 0;  // bumped whenever the probes are set anew
@@ -227,8 +228,8 @@ struct rt_tracer
     DeviceArray<int64_t> slotKey;
     DeviceArray<uint32_t> slotStart, slotCount;
     DeviceArray<double> probePoints;
-    DeviceArray<rtd::PackedCell> packedCells;
-    DeviceArray<rtd::NearEntry> nearEntries;
+    DeviceArray<rtd::ProbeBrick> bricks;
+    DeviceArray<rtd::DenseCell> denseCells;
     rtd::ProbeView probeView{};
     DeviceArray<float> storeRecords;
     uint64_t storeCapacity = 0;    // records the store takes (rt_set_store_limit may hold it below what was configured)
@@ -1295,7 +1296,7 @@ bool buildProbesOnDevice(rt_tracer* tracer, const double* probes, bool probesOnD
                          double keepRadius)
 {
     const int64_t reach = static_cast<int64_t>(std::ceil(keepRadius * invCellSize));
-    if (n == 0 || reach != 1 || n >= (1ull << 31) / 27)
+    if (n == 0 || reach != 1 || n >= (1ull << 29))  // a group's number and its place in a brick share 32 bits
     {
         return false;
     }
@@ -1315,7 +1316,7 @@ bool buildProbesOnDevice(rt_tracer* tracer, const double* probes, bool probesOnD
     orderIn.reserve(n);
     orderOut.reserve(n);
     flag.reserve(1);
-    scalars.reserve(2);
+    scalars.reserve(3);
     flag.zero(stream);
     scalars.zero(stream);
     check(hipMemcpyAsync(points.ptr, probes, 3 * n * sizeof(double),
@@ -1323,84 +1324,111 @@ bool buildProbesOnDevice(rt_tracer* tracer, const double* probes, bool probesOnD
           "hipMemcpyAsync probes");
     rtd::ProbeBuild build{points.ptr, n, invCellSize, keysIn.ptr, orderIn.ptr};
     rtd::launchProbeKeys(build, flag.ptr, stream);
+    size_t bytes = 0;
+    check(rtd::sortKeyPairs(nullptr, &bytes, keysIn.ptr, keysOut.ptr, orderIn.ptr, orderOut.ptr, n, stream), "sort size query");
+    space.heads.reserve(n);
+    space.cellOrdinal.reserve(n);
+    space.groupOrdinal.reserve(n);
+    size_t scanBytes = 0;
+    check(rtd::scanCounts(nullptr, &scanBytes, space.heads.ptr, space.cellOrdinal.ptr, static_cast<int64_t>(n), stream),
+          "scan size query");
+    scratch.reserve(std::max<size_t>(std::max(bytes, scanBytes), 1));
+    check(rtd::sortKeyPairs(scratch.ptr, &bytes, keysIn.ptr, keysOut.ptr, orderIn.ptr, orderOut.ptr, n, stream), "probe cell sort");
+    // scalars: [0] cells, [1] groups of 2 x 2 x 2 cells, [2] bricks
+    rtd::launchCountRuns(keysOut.ptr, n, 0, scalars.ptr, stream);
+    rtd::launchCountRuns(keysOut.ptr, n, 3, scalars.ptr + 1, stream);
+    // every probe's cell and group by number
+    rtd::launchRunHeads(keysOut.ptr, n, 0, space.heads.ptr, stream);
+    check(rtd::scanCounts(scratch.ptr, &scanBytes, space.heads.ptr, space.cellOrdinal.ptr, static_cast<int64_t>(n), stream),
+          "cell ordinal scan");
+    rtd::launchRunHeads(keysOut.ptr, n, 3, space.heads.ptr, stream);
+    check(rtd::scanCounts(scratch.ptr, &scanBytes, space.heads.ptr, space.groupOrdinal.ptr, static_cast<int64_t>(n), stream),
+          "group ordinal scan");
+    unsigned long long counts[2] = {0, 0};
     uint32_t unpackable = 0;
+    check(hipMemcpyAsync(counts, scalars.ptr, sizeof(counts), hipMemcpyDeviceToHost, stream), "hipMemcpyAsync runs");
     check(hipMemcpyAsync(&unpackable, flag.ptr, sizeof(unpackable), hipMemcpyDeviceToHost, stream), "hipMemcpyAsync flag");
     check(hipStreamSynchronize(stream), "hipStreamSynchronize");
     if (unpackable != 0)
     {
         return false;
     }
-    size_t bytes = 0;
-    check(rtd::sortKeyPairs(nullptr, &bytes, keysIn.ptr, keysOut.ptr, orderIn.ptr, orderOut.ptr, n, stream), "sort size query");
-    scratch.reserve(std::max<size_t>(bytes, 1));
-    check(rtd::sortKeyPairs(scratch.ptr, &bytes, keysIn.ptr, keysOut.ptr, orderIn.ptr, orderOut.ptr, n, stream), "probe cell sort");
-    rtd::launchCountRuns(keysOut.ptr, n, scalars.ptr, stream);
-    unsigned long long cellCount = 0;
-    check(hipMemcpyAsync(&cellCount, scalars.ptr, sizeof(cellCount), hipMemcpyDeviceToHost, stream), "hipMemcpyAsync runs");
-    check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+    const uint64_t cellCount = counts[0], groups = counts[1];
 
-    uint64_t slots = 16;
-    while (slots < 4 * cellCount + 1)
-    {
-        slots <<= 1;
-    }
-    tracer->slotKey.reserve(3 * slots);
-    tracer->slotStart.reserve(slots);
-    tracer->slotCount.reserve(slots);
-    tracer->probePoints.reserve(3 * n + 2);  // ... and at a probe position
-    tracer->slotCount.zero(stream);
-    tracer->packedCells.reserve(slots);
-    check(hipMemsetAsync(tracer->packedCells.ptr, 0xFF, slots * sizeof(rtd::PackedCell), stream), "hipMemsetAsync");
-    rtd::launchProbeTable(keysOut.ptr, orderOut.ptr, points.ptr, n, tracer->slotKey.ptr, tracer->slotStart.ptr,
-                          tracer->slotCount.ptr, tracer->packedCells.ptr, slots - 1, tracer->probePoints.ptr, stream);
-
+    tracer->probePoints.reserve(3 * n + 2);  // the keep test reads 32 bytes at a probe position
+    tracer->denseCells.reserve(cellCount);
+    rtd::launchDenseCells(keysOut.ptr, orderOut.ptr, space.cellOrdinal.ptr, points.ptr, n, tracer->denseCells.ptr,
+                          tracer->probePoints.ptr, stream);
     endSetupSpan(tracer, 1, indexSpan);
+
     const size_t filterSpan = beginSetupSpan(tracer, 2);
-    // the 27-neighbour filter: candidate keys, sorted, runs merged
-    const uint64_t candidates = 27 * cellCount;
-    DeviceArray<unsigned long long>&nearIn = space.nearIn, &nearOut = space.nearOut;
-    DeviceArray<uint32_t>&bitsIn = space.bitsIn, &bitsOut = space.bitsOut;
-    nearIn.reserve(candidates);
-    nearOut.reserve(candidates);
-    bitsIn.reserve(candidates);
-    bitsOut.reserve(candidates);
-    rtd::launchNeighbourKeys(keysOut.ptr, n, nearIn.ptr, bitsIn.ptr, scalars.ptr + 1, stream);
-    bytes = 0;
-    check(rtd::sortKeyPairs(nullptr, &bytes, nearIn.ptr, nearOut.ptr, bitsIn.ptr, bitsOut.ptr, candidates, stream),
-          "sort size query");
-    if (scratch.count < bytes) scratch.allocate(bytes);
-    check(rtd::sortKeyPairs(scratch.ptr, &bytes, nearIn.ptr, nearOut.ptr, bitsIn.ptr, bitsOut.ptr, candidates, stream),
-          "neighbour key sort");
-    check(hipMemsetAsync(scalars.ptr, 0, sizeof(unsigned long long), stream), "hipMemsetAsync");
-    rtd::launchCountRuns(nearOut.ptr, candidates, scalars.ptr, stream);
-    unsigned long long nearCount = 0;
-    check(hipMemcpyAsync(&nearCount, scalars.ptr, sizeof(nearCount), hipMemcpyDeviceToHost, stream), "hipMemcpyAsync runs");
-    check(hipStreamSynchronize(stream), "hipStreamSynchronize");
-    uint64_t nearSlots = 16;
-    while (nearSlots < 4 * nearCount + 1)
+    // the bricks: a record per group, the eight lists of the bricks the groups lie in, merged pair by pair
+    space.groupKey.reserve(groups);
+    space.groupOwn.reserve(groups);
+    space.groupFirst.reserve(groups);
+    rtd::launchCellGroups(keysOut.ptr, space.cellOrdinal.ptr, space.groupOrdinal.ptr, n, space.groupKey.ptr, space.groupOwn.ptr,
+                          space.groupFirst.ptr, stream);
+    const uint64_t total = 8 * groups;
+    space.listKeys[0].reserve(total);
+    space.listKeys[1].reserve(total);
+    space.listEntries[0].reserve(total);
+    space.listEntries[1].reserve(total);
+    rtd::launchBrickLists(space.groupKey.ptr, groups, space.listKeys[0].ptr, space.listEntries[0].ptr, stream);
+    size_t mergeBytes = 0;
+    for (uint64_t width = groups; width < total; width *= 2)
     {
-        nearSlots <<= 1;
+        size_t need = 0;
+        check(rtd::mergeKeyPairs(nullptr, &need, space.listKeys[0].ptr, space.listEntries[0].ptr, width, space.listKeys[0].ptr,
+                                 space.listEntries[0].ptr, width, space.listKeys[1].ptr, space.listEntries[1].ptr, stream),
+              "merge size query");
+        mergeBytes = std::max(mergeBytes, need);
     }
-    tracer->nearEntries.reserve(nearSlots + 2);  // the keep test reads 40 bytes at an entry
-    check(hipMemsetAsync(tracer->nearEntries.ptr, 0xFF, nearSlots * sizeof(rtd::NearEntry), stream), "hipMemsetAsync");
-    rtd::launchNeighbourTable(nearOut.ptr, bitsOut.ptr, candidates, tracer->nearEntries.ptr, nearSlots - 1, stream);
+    space.mergeScratch.reserve(std::max<size_t>(mergeBytes, 1));
+    int from = 0;
+    for (uint64_t width = groups; width < total; width *= 2, from ^= 1)
+    {
+        for (uint64_t at = 0; at < total; at += 2 * width)
+        {
+            size_t need = mergeBytes;
+            check(rtd::mergeKeyPairs(space.mergeScratch.ptr, &need, space.listKeys[from].ptr + at, space.listEntries[from].ptr + at,
+                                     width, space.listKeys[from].ptr + at + width, space.listEntries[from].ptr + at + width, width,
+                                     space.listKeys[from ^ 1].ptr + at, space.listEntries[from ^ 1].ptr + at, stream),
+                  "brick list merge");
+        }
+    }
+    rtd::launchCountRuns(space.listKeys[from].ptr, total, 0, scalars.ptr + 2, stream);
+    unsigned long long brickCount = 0;
+    check(hipMemcpyAsync(&brickCount, scalars.ptr + 2, sizeof(brickCount), hipMemcpyDeviceToHost, stream), "hipMemcpyAsync bricks");
+    check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+    uint64_t brickSlots = 16;
+    while (brickSlots < 3 * brickCount + 1)
+    {
+        brickSlots <<= 1;
+    }
+    tracer->bricks.reserve(brickSlots);
+    check(hipMemsetAsync(tracer->bricks.ptr, 0xFF, brickSlots * sizeof(rtd::ProbeBrick), stream), "hipMemsetAsync");
+    rtd::launchBricks(space.listKeys[from].ptr, space.listEntries[from].ptr, total, space.groupOwn.ptr, space.groupFirst.ptr,
+                      tracer->bricks.ptr, brickSlots - 1, stream);
     check(hipGetLastError(), "probe grid build");
     endSetupSpan(tracer, 2, filterSpan);
     check(hipStreamSynchronize(stream), "hipStreamSynchronize");
 
     rtd::ProbeView& pv = tracer->probeView;
-    pv.slotKey = tracer->slotKey.ptr;
-    pv.slotStart = tracer->slotStart.ptr;
-    pv.slotCount = tracer->slotCount.ptr;
+    pv.slotKey = nullptr;
+    pv.slotStart = nullptr;
+    pv.slotCount = nullptr;
     pv.points = tracer->probePoints.ptr;
-    pv.slotMask = slots - 1;
+    pv.slotMask = 0;
     pv.probeCount = n;
     pv.invCellSize = invCellSize;
     pv.keepRadius = keepRadius;
     pv.reach = reach;
-    pv.nearMask = nearSlots - 1;
-    pv.packedCells = tracer->packedCells.ptr;
-    pv.nearEntries = tracer->nearEntries.ptr;
+    pv.brickMask = brickSlots - 1;
+    pv.bricks = tracer->bricks.ptr;
+    pv.cells = tracer->denseCells.ptr;
+    tracer->slotKey.release();
+    tracer->slotStart.release();
+    tracer->slotCount.release();
     return true;
 }
 
@@ -1831,13 +1859,13 @@ void setProbes(rt_tracer* tracer, const double* probes, bool probesOnDevice, uin
     pv.reach = static_cast<int64_t>(std::ceil(keepRadius * invCellSize));
     require(pv.reach <= 64, "keep radius spans too many probe cells");
 
-    // no neighbourhood filter on this path (the device build above makes it whenever it applies):
+    // the general form of the grid (the device build above makes the brick form whenever it applies):
     // the keep test scans the cells within reach
-    pv.nearMask = 0;
-    pv.packedCells = nullptr;
-    pv.nearEntries = nullptr;
-    tracer->packedCells.release();
-    tracer->nearEntries.release();
+    pv.brickMask = 0;
+    pv.bricks = nullptr;
+    pv.cells = nullptr;
+    tracer->bricks.release();
+    tracer->denseCells.release();
     tracer->probesSet = true;
     tracer->probeVersion += 1;
 }

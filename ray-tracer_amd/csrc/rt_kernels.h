@@ -7,44 +7,52 @@
 namespace rtd
 {
 
-// Sink A: the probe keep-test grid (reference src/ProbeIndex.cpp) as an open-addressed
-// hash table in HBM, and the raw bounce store (reference src/BounceStore.cpp).
-struct PackedCell;
-struct NearEntry;
+// Sink A: the probe keep-test grid (reference src/ProbeIndex.cpp) in HBM, and the raw bounce store
+// (reference src/BounceStore.cpp).  The grid has two forms.
+//
+// The general form is an open-addressed table of cells (slotKey / slotStart / slotCount): the keep
+// test looks up every cell within reach.
+//
+// The usual case — a keep radius of one cell, cell coordinates that pack into 3 x 21 bits — is built
+// on the device in a form that costs one table lookup per test: the occupied cells lie in one dense
+// array (`cells`, each with its first probe), ordered by (x >> 1, y >> 1, z, y & 1, x & 1), and a table of
+// BRICKS tells where.  A brick is a block of 4 x 4 x 4 cells that starts at even coordinates, so the
+// bricks overlap and the 27 cells around any cell c lie inside the one brick that starts at
+// ((c - 1) >> 1) * 2.  Its entry holds one bit per cell (bit x + 4 y + 16 z in brick coordinates, CLEAR
+// where the cell holds probes) and, for each of its four columns of 2 x 2 x 4 cells, the place in
+// `cells` of the column's first occupied cell: the cells of a column follow each other in `cells` in
+// the order of their bits, so a cell's place is its column's base plus the number of occupied cells
+// of the column below its bit.  Only bricks that hold a probe have an entry.
+struct ProbeBrick;
+struct DenseCell;
 
 struct ProbeView
 {
     const int64_t* slotKey;      // [slots][3] cell coordinates
     const uint32_t* slotStart;   // [slots] first probe of the cell in `points`
     const uint32_t* slotCount;   // [slots] 0 = empty slot
-    const double* points;        // [probes][3], grouped by cell
+    const double* points;        // [probes][3], grouped by cell (one more double may be read behind the last)
     uint64_t slotMask;           // slots - 1 (power of two)
     uint64_t probeCount;
     double invCellSize;
     double keepRadius;
     int64_t reach;               // ceil(keepRadius * invCellSize)
-    // Neighbourhood filter (only when reach == 1 and every probe cell packs into 3 x 21
-    // bits; nearMask == 0 otherwise): every cell that has an occupied cell among its 27
-    // neighbours, with one bit per occupied neighbour, bit (dz+1)*9 + (dy+1)*3 + (dx+1).
-    uint64_t nearMask;
-    // Both tables as single entries (one load per lookup): packedCells[slot] mirrors slotKey /
-    // slotStart / slotCount and carries the cell's first probe, nearEntries[slot] is the filter.
-    // A free slot holds kEmptyKey.
-    const PackedCell* packedCells;
-    const NearEntry* nearEntries;       // [nearMask + 1]
+    uint64_t brickMask;          // brick slots - 1 (power of two); 0: the general form
+    const ProbeBrick* bricks;    // [brickMask + 1], a free slot holds kEmptyKey
+    const DenseCell* cells;
 };
 
-struct alignas(16) PackedCell  // 48 bytes
+struct alignas(16) ProbeBrick  // 32 bytes
 {
-    unsigned long long key;  // packed cell coordinates
-    uint32_t start, count;   // its probes in `points`
-    double first[3];         // the first of them (most cells hold one probe: no second read)
+    unsigned long long key;     // packed brick coordinates (in units of two cells)
+    unsigned long long vacant;  // bit x + 4 y + 16 z: clear where the cell holds probes
+    uint32_t base[4];           // column (x >> 1) + 2 (y >> 1): the place of its first occupied cell in `cells`
 };
 
-struct alignas(16) NearEntry
+struct alignas(16) DenseCell  // 32 bytes
 {
-    unsigned long long key;
-    uint32_t bits, reserved;
+    double first[3];        // the first of the cell's probes (most cells hold one probe: no second read)
+    uint32_t start, count;  // all of them in `points`
 };
 
 // The store drops what arrives beyond its capacity (reference src/BounceStore.cpp:21-33), and which
@@ -290,14 +298,26 @@ void launchProbePositions(const GatherPoint* points, uint64_t n, double* positio
 // stable ascending sort of (keys, order) pairs of any length below 2^31
 hipError_t sortKeyPairs(void* scratch, size_t* scratchBytes, const unsigned long long* keysIn, unsigned long long* keysOut,
                         const uint32_t* orderIn, uint32_t* orderOut, uint64_t n, hipStream_t stream);
-void launchCountRuns(const unsigned long long* sortedKeys, uint64_t n, unsigned long long* runs, hipStream_t stream);
-void launchProbeTable(const unsigned long long* sortedKeys, const uint32_t* sortedOrder, const double* points, uint64_t n,
-                      int64_t* slotKey, uint32_t* slotStart, uint32_t* slotCount, PackedCell* packedCells,
-                      uint64_t slotMask, double* groupedPoints, hipStream_t stream);
-void launchNeighbourKeys(const unsigned long long* sortedKeys, uint64_t n, unsigned long long* outKeys,
-                         uint32_t* outBits, unsigned long long* cursor, hipStream_t stream);
-void launchNeighbourTable(const unsigned long long* sortedKeys, const uint32_t* sortedBits, uint64_t n,
-                          NearEntry* nearEntries, uint64_t nearMask, hipStream_t stream);
+// runs[0] += the number of runs of equal (key >> shift) in the sorted keys
+void launchCountRuns(const unsigned long long* sortedKeys, uint64_t n, int shift, unsigned long long* runs, hipStream_t stream);
+// heads[i] = 1 where sortedKeys[i] starts a run of equal (key >> shift), else 0
+void launchRunHeads(const unsigned long long* sortedKeys, uint64_t n, int shift, uint32_t* heads, hipStream_t stream);
+// the probes in cell order and the dense array of cells (ordinal[i]: the number of cells before probe i's)
+void launchDenseCells(const unsigned long long* sortedKeys, const uint32_t* sortedOrder, const uint64_t* ordinal,
+                      const double* points, uint64_t n, DenseCell* cells, double* groupedPoints, hipStream_t stream);
+// The bricks (see ProbeView) are gathered from the groups of 2 x 2 x 2 cells: a record per group (fewer than
+// 2^29 of them), eight sorted lists of (brick, group) — list s in [s * groups, (s + 1) * groups) — that
+// the caller merges with mergeKeyPairs, and a table entry per run of equal bricks in the merged list.
+void launchCellGroups(const unsigned long long* sortedKeys, const uint64_t* cellOrdinal, const uint64_t* groupOrdinal, uint64_t n,
+                      unsigned long long* groupKey, uint32_t* groupOwn, uint32_t* groupFirst, hipStream_t stream);
+void launchBrickLists(const unsigned long long* groupKey, uint64_t groups, unsigned long long* listKeys, uint32_t* listEntries,
+                      hipStream_t stream);
+hipError_t mergeKeyPairs(void* scratch, size_t* scratchBytes, const unsigned long long* keysA, const uint32_t* valuesA, uint64_t nA,
+                         const unsigned long long* keysB, const uint32_t* valuesB, uint64_t nB, unsigned long long* keysOut,
+                         uint32_t* valuesOut, hipStream_t stream);
+// fills the brick table (every byte 0xFF before) from the merged list
+void launchBricks(const unsigned long long* mergedKeys, const uint32_t* mergedEntries, uint64_t total, const uint32_t* groupOwn,
+                  const uint32_t* groupFirst, ProbeBrick* bricks, uint64_t brickMask, hipStream_t stream);
 void launchProbeTest(const ProbeView& probes, int64_t n, const double* points, uint8_t* out, hipStream_t stream);
 
 // ---- which records an overflowing store keeps (rt_store.hip) ----

@@ -19,6 +19,7 @@
 #include <cstdlib>
 
 #include <hipcub/hipcub.hpp>
+#include <hipcub/device/device_merge.hpp>
 #include <rocprim/rocprim.hpp>
 
 namespace rtd
@@ -113,13 +114,23 @@ RT_DEV unsigned long long packProbeCell(int64_t kx, int64_t ky, int64_t kz)
            static_cast<unsigned long long>(kz + kPackLimit);
 }
 
-// The keep test through the neighbourhood filter, as one loop with ONE load per trip.  Every lane
-// walks its own chain of dependent reads (filter entry -> cell entry -> probe points -> next cell
-// ...), and a wave pays a memory round trip per trip of whichever loop it is in; nested per-table
-// loops cost the sum of the longest chain of each loop over the wave, this loop costs the longest
-// total of one lane.  All three tables are read with the same 40-byte load (a filter entry and
-// what follows it, a cell entry with the cell's first probe, or a probe position and what
-// follows it), so the filter and the probe positions carry padding at their ends.
+// The key the probes are sorted by when the grid is built in its brick form: cells ordered by
+// (x >> 1, y >> 1, z, y & 1, x & 1), the order of the dense cell array (see ProbeView).
+RT_DEV unsigned long long orderedProbeCell(int64_t kx, int64_t ky, int64_t kz)
+{
+    const unsigned long long x = static_cast<unsigned long long>(kx + kPackLimit);
+    const unsigned long long y = static_cast<unsigned long long>(ky + kPackLimit);
+    const unsigned long long z = static_cast<unsigned long long>(kz + kPackLimit);
+    return ((x >> 1) << 43) | ((y >> 1) << 23) | (z << 2) | ((y & 1) << 1) | (x & 1);
+}
+
+// The keep test through the brick table, as one loop with ONE load per trip.  Every lane walks its own
+// chain of dependent reads (brick entry -> cell -> further probes of the cell -> next cell ...), and a
+// wave pays a memory round trip per trip of whichever loop it is in; nested per-table loops cost the sum
+// of the longest chain of each loop over the wave, this loop costs the longest total of one lane.  All
+// three arrays are read with the same 32-byte load (a brick entry, a cell with its first probe, or a
+// probe position and what follows it).  The brick entry is the only hashed lookup: it tells which of the
+// 27 cells around p hold probes and where each of them lies in the dense cell array.
 // Order: the deposit's own cell first (on a surface the camera sees it usually holds a probe in
 // reach), then the other occupied cells (their order made no measurable difference), skipping
 // those whose box lies farther from p than the
@@ -129,85 +140,74 @@ RT_DEV bool anyProbeInNeighbourhood(const ProbeView& pv, const Vec& p, double r2
 {
     typedef uint32_t Uint4At8 __attribute__((ext_vector_type(4), aligned(8)));
     constexpr uint32_t kCentreBit = 1u << 13;
-    enum { kFilter = 0, kCell = 1, kPoints = 2, kFinished = 3 };
+    enum { kBrick = 0, kCell = 1, kPoints = 2, kFinished = 3 };
     const double fx = p.x * pv.invCellSize - static_cast<double>(cx);
     const double fy = p.y * pv.invCellSize - static_cast<double>(cy);
     const double fz = p.z * pv.invCellSize - static_cast<double>(cz);
     const double reach2 = r2 * pv.invCellSize * pv.invCellSize * (1.0 + 1e-6);
+    // the brick that holds the 27 cells around (cx, cy, cz), and where in it the first of them lies (0 or 1)
+    const int64_t mx = (cx - 1) >> 1, my = (cy - 1) >> 1, mz = (cz - 1) >> 1;
+    const int ox = static_cast<int>(cx - 1 - 2 * mx), oy = static_cast<int>(cy - 1 - 2 * my), oz = static_cast<int>(cz - 1 - 2 * mz);
 
-    int phase = kFilter;
+    int phase = kBrick;
     bool found = false;
     uint32_t bits = 0;       // occupied neighbour cells not visited yet
     uint32_t remaining = 0;  // probes of the current cell not tested yet
-    unsigned long long key = packProbeCell(cx, cy, cz);
-    uint64_t slot = cellHash(cx, cy, cz) & pv.nearMask;
-    const char* address = reinterpret_cast<const char*>(pv.nearEntries + slot);
+    unsigned long long occupied = 0;
+    uint32_t base0 = 0, base1 = 0, base2 = 0, base3 = 0;
+    const unsigned long long key = packProbeCell(mx, my, mz);
+    uint64_t slot = cellHash(mx, my, mz) & pv.brickMask;
+    const char* address = reinterpret_cast<const char*>(pv.bricks + slot);
     while (phase != kFinished)
     {
         RT_DIAG_TRIP(12);
         const Uint4At8 head = *reinterpret_cast<const Uint4At8*>(address);
         const Uint4At8 mid = *reinterpret_cast<const Uint4At8*>(address + 16);
-        const unsigned long long tail = *reinterpret_cast<const unsigned long long*>(address + 32);
         const unsigned long long first = (static_cast<unsigned long long>(head.y) << 32) | head.x;
         const unsigned long long second = (static_cast<unsigned long long>(head.w) << 32) | head.z;
         const unsigned long long third = (static_cast<unsigned long long>(mid.y) << 32) | mid.x;
-        const unsigned long long fourth = (static_cast<unsigned long long>(mid.w) << 32) | mid.z;
-        bool nextCell = false, testProbe = false;
-        double qx = 0.0, qy = 0.0, qz = 0.0;
-        if (phase == kPoints)
+        bool nextCell = false;
+        if (phase == kBrick)
         {
-            qx = __builtin_bit_cast(double, first);
-            qy = __builtin_bit_cast(double, second);
-            qz = __builtin_bit_cast(double, third);
-            testProbe = true;
-        }
-        else if (first == key)
-        {
-            if (phase == kFilter)
+            if (first == key)
             {
-                bits = head.z;
+                occupied = ~second;
+                base0 = mid.x;
+                base1 = mid.y;
+                base2 = mid.z;
+                base3 = mid.w;
+                // the 3 x 3 x 3 window of the brick's bits around the cell: bit iz * 9 + iy * 3 + ix
+#pragma unroll
+                for (int iz = 0; iz < 3; ++iz)
+                {
+#pragma unroll
+                    for (int iy = 0; iy < 3; ++iy)
+                    {
+                        const uint32_t row = static_cast<uint32_t>(occupied >> (ox + 4 * (oy + iy) + 16 * (oz + iz))) & 7u;
+                        bits |= row << (iz * 9 + iy * 3);
+                    }
+                }
                 nextCell = true;
             }
-            else if (head.w == 0)
-            {
-                nextCell = true;
-            }
-            else
-            {
-                // the cell's entry carries its first probe; the others follow it in `points`
-                qx = __builtin_bit_cast(double, third);
-                qy = __builtin_bit_cast(double, fourth);
-                qz = __builtin_bit_cast(double, tail);
-                testProbe = true;
-                remaining = head.w;
-                phase = kPoints;
-                address = reinterpret_cast<const char*>(pv.points + 3ull * head.z);
-            }
-        }
-        else if (first == kEmptyKey)
-        {
-            if (phase == kFilter)
+            else if (first == kEmptyKey)
             {
                 phase = kFinished;  // no occupied cell around p
             }
             else
             {
-                nextCell = true;
+                slot = (slot + 1) & pv.brickMask;
+                address = reinterpret_cast<const char*>(pv.bricks + slot);
             }
-        }
-        else if (phase == kFilter)
-        {
-            slot = (slot + 1) & pv.nearMask;
-            address = reinterpret_cast<const char*>(pv.nearEntries + slot);
         }
         else
         {
-            slot = (slot + 1) & pv.slotMask;
-            address = reinterpret_cast<const char*>(pv.packedCells + slot);
-        }
-        if (testProbe)
-        {
-            const double ddx = qx - p.x, ddy = qy - p.y, ddz = qz - p.z;
+            if (phase == kCell)
+            {
+                remaining = mid.w;
+            }
+            const double ddx = __builtin_bit_cast(double, first) - p.x;
+            const double ddy = __builtin_bit_cast(double, second) - p.y;
+            const double ddz = __builtin_bit_cast(double, third) - p.z;
             if (ddx * ddx + ddy * ddy + ddz * ddz <= r2)
             {
                 found = true;
@@ -216,6 +216,12 @@ RT_DEV bool anyProbeInNeighbourhood(const ProbeView& pv, const Vec& p, double r2
             else if (--remaining == 0)
             {
                 nextCell = true;
+            }
+            else if (phase == kCell)
+            {
+                // the cell's entry carries its first probe; the others follow it in `points`
+                phase = kPoints;
+                address = reinterpret_cast<const char*>(pv.points + 3ull * (mid.z + 1u));
             }
             else
             {
@@ -237,10 +243,14 @@ RT_DEV bool anyProbeInNeighbourhood(const ProbeView& pv, const Vec& p, double r2
                 {
                     continue;
                 }
-                const int64_t kx = cx + ix - 1, ky = cy + iy - 1, kz = cz + iz - 1;
-                key = packProbeCell(kx, ky, kz);
-                slot = cellHash(kx, ky, kz) & pv.slotMask;
-                address = reinterpret_cast<const char*>(pv.packedCells + slot);
+                // the cell's place: its column's base + the occupied cells of the column below its bit
+                const int bx = ox + ix, by = oy + iy, bz = oz + iz;
+                const int column = (bx >> 1) + 2 * (by >> 1);
+                const unsigned long long below = (1ull << (bx + 4 * by + 16 * bz)) - 1ull;
+                const unsigned long long inColumn = 0x0033003300330033ull << (2 * (bx >> 1) + 8 * (by >> 1));
+                const uint32_t base = column == 0 ? base0 : (column == 1 ? base1 : (column == 2 ? base2 : base3));
+                const uint32_t place = base + static_cast<uint32_t>(__builtin_popcountll(occupied & inColumn & below));
+                address = reinterpret_cast<const char*>(pv.cells + place);
                 phase = kCell;
                 break;
             }
@@ -264,7 +274,7 @@ RT_DEV bool anyProbeWithin(const ProbeView& pv, const Vec& p)
     const int64_t cx = static_cast<int64_t>(__builtin_floor(p.x * pv.invCellSize));
     const int64_t cy = static_cast<int64_t>(__builtin_floor(p.y * pv.invCellSize));
     const int64_t cz = static_cast<int64_t>(__builtin_floor(p.z * pv.invCellSize));
-    if (pv.nearMask != 0)
+    if (pv.brickMask != 0)
     {
         // probe cells lie strictly inside the packable range, so a cell on or beyond
         // its border has no occupied neighbour
@@ -2386,10 +2396,9 @@ __global__ void probePositionsKernel(const GatherPoint* points, uint64_t n, doub
 
 // ---------------------------------------------------------------- probe grid build
 // ProbeIndex's constructor (reference src/ProbeIndex.cpp:5-25) hashes every probe into an
-// unordered_map of cells.  Here the probes are keyed by packed cell, sorted, and the runs of
-// equal keys become the cells of an open-addressed table; the 27-neighbour occupancy filter
-// is built the same way from the 27 keys around every occupied cell (keys: packProbeCell, x in the
-// high bits).
+// unordered_map of cells.  Here the probes are keyed by cell (orderedProbeCell), sorted, and the runs of
+// equal keys become the dense array of cells; the bricks (see ProbeView) are entered into their table
+// by the groups of 2 x 2 x 2 cells, each of which lies in eight bricks.
 __global__ void probeKeysKernel(const ProbeBuild b, uint32_t* unpackable)
 {
     const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -2397,20 +2406,20 @@ __global__ void probeKeysKernel(const ProbeBuild b, uint32_t* unpackable)
     const int64_t x = static_cast<int64_t>(__builtin_floor(b.points[3 * i + 0] * b.invCellSize));
     const int64_t y = static_cast<int64_t>(__builtin_floor(b.points[3 * i + 1] * b.invCellSize));
     const int64_t z = static_cast<int64_t>(__builtin_floor(b.points[3 * i + 2] * b.invCellSize));
-    const int64_t lim = kPackLimit - 2;  // leaves room for the neighbours of a border cell
+    const int64_t lim = kPackLimit - 4;  // leaves room for the bricks around a border cell
     const bool fits = x > -lim && x < lim && y > -lim && y < lim && z > -lim && z < lim;
     if (!fits)
     {
         atomicAdd(unpackable, 1u);
     }
-    b.keys[i] = fits ? packProbeCell(x, y, z) : kEmptyKey;
+    b.keys[i] = fits ? orderedProbeCell(x, y, z) : kEmptyKey;
     b.order[i] = static_cast<uint32_t>(i);
 }
 
-// runs[0] += number of runs of equal keys (= occupied cells); a block counts 16 keys per
+// runs[0] += number of runs of equal (key >> shift); a block counts 16 keys per
 // thread and adds once, so that the one counter sees a few thousand atomics, not millions
 constexpr int kRunsPerThread = 16;
-__global__ void countRunsKernel(const unsigned long long* keys, uint64_t n, unsigned long long* runs)
+__global__ void countRunsKernel(const unsigned long long* keys, uint64_t n, int shift, unsigned long long* runs)
 {
     __shared__ unsigned int blockHeads;
     if (threadIdx.x == 0) blockHeads = 0;
@@ -2420,7 +2429,7 @@ __global__ void countRunsKernel(const unsigned long long* keys, uint64_t n, unsi
     for (int k = 0; k < kRunsPerThread; ++k)
     {
         const uint64_t i = blockBase + static_cast<uint64_t>(k) * blockDim.x + threadIdx.x;
-        if (i < n && (i == 0 || keys[i] != keys[i - 1])) heads += 1;
+        if (i < n && (i == 0 || (keys[i] >> shift) != (keys[i - 1] >> shift))) heads += 1;
     }
 #pragma unroll
     for (int offset = 32; offset > 0; offset >>= 1)
@@ -2432,18 +2441,27 @@ __global__ void countRunsKernel(const unsigned long long* keys, uint64_t n, unsi
     if (threadIdx.x == 0 && blockHeads != 0) atomicAdd(runs, static_cast<unsigned long long>(blockHeads));
 }
 
-// every probe is copied to its place in cell order; the first probe of every cell enters the
-// cell into the table (a slot is claimed through its count, 0 = free)
-__global__ void probeTableKernel(const unsigned long long* keys, const uint32_t* order, const double* points, uint64_t n,
-                                 int64_t* slotKey, uint32_t* slotStart, uint32_t* slotCount, PackedCell* packedCells,
-                                 uint64_t slotMask, double* grouped)
+__global__ void runHeadsKernel(const unsigned long long* keys, uint64_t n, int shift, uint32_t* heads)
+{
+    const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    heads[i] = (i == 0 || (keys[i] >> shift) != (keys[i - 1] >> shift)) ? 1u : 0u;
+}
+
+// every probe is copied to its place in cell order; the first probe of every cell writes the cell
+__global__ void denseCellsKernel(const unsigned long long* keys, const uint32_t* order, const uint64_t* ordinal,
+                                 const double* points, uint64_t n, DenseCell* cells, double* grouped)
 {
     const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t src = order[i];
-    grouped[3 * i + 0] = points[3 * static_cast<uint64_t>(src) + 0];
-    grouped[3 * i + 1] = points[3 * static_cast<uint64_t>(src) + 1];
-    grouped[3 * i + 2] = points[3 * static_cast<uint64_t>(src) + 2];
+    DenseCell cell;
+    cell.first[0] = points[3 * static_cast<uint64_t>(src) + 0];
+    cell.first[1] = points[3 * static_cast<uint64_t>(src) + 1];
+    cell.first[2] = points[3 * static_cast<uint64_t>(src) + 2];
+    grouped[3 * i + 0] = cell.first[0];
+    grouped[3 * i + 1] = cell.first[1];
+    grouped[3 * i + 2] = cell.first[2];
     const unsigned long long key = keys[i];
     if (i != 0 && keys[i - 1] == key)
     {
@@ -2454,83 +2472,88 @@ __global__ void probeTableKernel(const unsigned long long* keys, const uint32_t*
     {
         count += 1;
     }
-    const int64_t x = static_cast<int64_t>(key >> 42) - kPackLimit;
-    const int64_t y = static_cast<int64_t>((key >> 21) & ((1ull << 21) - 1)) - kPackLimit;
-    const int64_t z = static_cast<int64_t>(key & ((1ull << 21) - 1)) - kPackLimit;
-    uint64_t slot = cellHash(x, y, z) & slotMask;
-    while (atomicCAS(slotCount + slot, 0u, count) != 0u)
-    {
-        slot = (slot + 1) & slotMask;
-    }
-    slotKey[3 * slot + 0] = x;
-    slotKey[3 * slot + 1] = y;
-    slotKey[3 * slot + 2] = z;
-    slotStart[slot] = static_cast<uint32_t>(i);
-    PackedCell cell;
-    cell.key = key;
     cell.start = static_cast<uint32_t>(i);
     cell.count = count;
-    cell.first[0] = grouped[3 * i + 0];
-    cell.first[1] = grouped[3 * i + 1];
-    cell.first[2] = grouped[3 * i + 2];
-    packedCells[slot] = cell;
+    cells[ordinal[i]] = cell;
 }
 
-// for every occupied cell, the 27 cells around it, each with the bit that says "my neighbour
-// at the opposite offset is occupied"
-__global__ void neighbourKeysKernel(const unsigned long long* keys, uint64_t n, unsigned long long* outKeys,
-                                    uint32_t* outBits, unsigned long long* cursor)
-{
-    const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    const bool head = i < n && (i == 0 || keys[i] != keys[i - 1]);
-    const unsigned long long mask = __ballot(head);
-    if (mask == 0) return;
-    unsigned long long base = 0;
-    const int leader = __builtin_ctzll(mask);
-    if (static_cast<int>(threadIdx.x & 63) == leader)
-    {
-        base = atomicAdd(cursor, 27ull * static_cast<unsigned long long>(__builtin_popcountll(mask)));
-    }
-    base = __shfl(base, leader, 64);
-    if (!head) return;
-    const unsigned long long at = base + 27ull * lanesBelow(mask);
-    const unsigned long long key = keys[i];
-    const int64_t x = static_cast<int64_t>(key >> 42) - kPackLimit;
-    const int64_t y = static_cast<int64_t>((key >> 21) & ((1ull << 21) - 1)) - kPackLimit;
-    const int64_t z = static_cast<int64_t>(key & ((1ull << 21) - 1)) - kPackLimit;
-    int k = 0;
-    for (int dz = -1; dz <= 1; ++dz)
-        for (int dy = -1; dy <= 1; ++dy)
-            for (int dx = -1; dx <= 1; ++dx)
-            {
-                outKeys[at + k] = packProbeCell(x + dx, y + dy, z + dz);
-                outBits[at + k] = 1u << ((1 - dz) * 9 + (1 - dy) * 3 + (1 - dx));
-                k += 1;
-            }
-}
-
-// sorted neighbour keys: the first of every run ORs the run's bits and enters the table
-__global__ void neighbourTableKernel(const unsigned long long* keys, const uint32_t* bits, uint64_t n,
-                                     NearEntry* nearEntries, uint64_t nearMask)
+// A group is the run of sorted keys that agree above their low three bits: the cells of one block of
+// 2 x 2 x 2 (x >> 1, y >> 1, z >> 1).  The group at (hx, hy, hz) lies in the eight bricks at (hx - sx, hy - sy,
+// hz - sz), s = 0 or 1 per axis (brick coordinates are in units of two cells).  No atomic operation
+// gathers a brick's eight groups: the groups are in sorted order, so the list of the bricks they lie in
+// at one s is sorted too (a packed key minus a constant), the eight lists are merged, and the entries of
+// one brick then follow each other.
+constexpr int kGroupIndexBits = 29;
+__global__ void cellGroupsKernel(const unsigned long long* keys, const uint64_t* cellOrdinal, const uint64_t* groupOrdinal,
+                                 uint64_t n, unsigned long long* groupKey, uint32_t* groupOwn, uint32_t* groupFirst)
 {
     const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const unsigned long long key = keys[i];
-    if (i != 0 && keys[i - 1] == key) return;
-    uint32_t all = 0;
-    for (uint64_t j = i; j < n && keys[j] == key; ++j)
+    const unsigned long long head = keys[i];
+    if (i != 0 && (keys[i - 1] >> 3) == (head >> 3)) return;
+    // the group's cells as bits of a brick whose origin is the group's: bit x + 4 y + 16 z, x, y, z in 0..1
+    uint32_t own = 0;
+    for (uint64_t j = i; j < n && (keys[j] >> 3) == (head >> 3); ++j)
     {
-        all |= bits[j];
+        const unsigned long long k = keys[j];
+        own |= 1u << ((k & 1) + 4 * ((k >> 1) & 1) + 16 * ((k >> 2) & 1));
     }
-    const int64_t x = static_cast<int64_t>(key >> 42) - kPackLimit;
-    const int64_t y = static_cast<int64_t>((key >> 21) & ((1ull << 21) - 1)) - kPackLimit;
-    const int64_t z = static_cast<int64_t>(key & ((1ull << 21) - 1)) - kPackLimit;
-    uint64_t slot = cellHash(x, y, z) & nearMask;
-    while (atomicCAS(&nearEntries[slot].key, kEmptyKey, key) != kEmptyKey)
+    const int64_t hx = static_cast<int64_t>(head >> 43) - kPackLimit / 2;
+    const int64_t hy = static_cast<int64_t>((head >> 23) & ((1ull << 20) - 1)) - kPackLimit / 2;
+    const int64_t hz = static_cast<int64_t>((head >> 3) & ((1ull << 20) - 1)) - kPackLimit / 2;
+    const uint64_t g = groupOrdinal[i];
+    groupKey[g] = packProbeCell(hx, hy, hz);
+    groupOwn[g] = own;
+    groupFirst[g] = static_cast<uint32_t>(cellOrdinal[i]);
+}
+
+// list s (entries [s * groups, (s + 1) * groups)): the brick each group lies in at offset s, and (s, group)
+__global__ void brickListsKernel(const unsigned long long* groupKey, uint64_t groups, unsigned long long* listKeys,
+                                 uint32_t* listEntries)
+{
+    const uint64_t t = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (t >= 8 * groups) return;
+    const uint64_t s = t / groups, g = t - s * groups;
+    listKeys[t] = groupKey[g] - ((s & 1) << 42) - (((s >> 1) & 1) << 21) - (s >> 2);
+    listEntries[t] = static_cast<uint32_t>(g) | (static_cast<uint32_t>(s) << kGroupIndexBits);
+}
+
+// the merged lists: the first entry of every brick gathers the brick and enters it into the table
+__global__ void bricksKernel(const unsigned long long* keys, const uint32_t* entries, uint64_t total, const uint32_t* groupOwn,
+                             const uint32_t* groupFirst, ProbeBrick* bricks, uint64_t brickMask)
+{
+    const uint64_t t = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const unsigned long long key = keys[t];
+    if (t != 0 && keys[t - 1] == key) return;
+    unsigned long long vacant = ~0ull;
+    uint32_t base0 = ~0u, base1 = ~0u, base2 = ~0u, base3 = ~0u;
+    for (uint64_t u = t; u < total && keys[u] == key; ++u)
     {
-        slot = (slot + 1) & nearMask;
+        const uint32_t entry = entries[u];
+        const uint32_t g = entry & ((1u << kGroupIndexBits) - 1u);
+        const int sx = (entry >> kGroupIndexBits) & 1, sy = (entry >> (kGroupIndexBits + 1)) & 1, sz = entry >> (kGroupIndexBits + 2);
+        vacant &= ~(static_cast<unsigned long long>(groupOwn[g]) << (2 * sx + 8 * sy + 32 * sz));
+        const uint32_t first = groupFirst[g];
+        const int column = sx + 2 * sy;
+        base0 = column == 0 ? min(base0, first) : base0;
+        base1 = column == 1 ? min(base1, first) : base1;
+        base2 = column == 2 ? min(base2, first) : base2;
+        base3 = column == 3 ? min(base3, first) : base3;
     }
-    nearEntries[slot].bits = all;
+    const int64_t mx = static_cast<int64_t>(key >> 42) - kPackLimit;
+    const int64_t my = static_cast<int64_t>((key >> 21) & ((1ull << 21) - 1)) - kPackLimit;
+    const int64_t mz = static_cast<int64_t>(key & ((1ull << 21) - 1)) - kPackLimit;
+    uint64_t slot = cellHash(mx, my, mz) & brickMask;
+    while (atomicCAS(&bricks[slot].key, kEmptyKey, key) != kEmptyKey)
+    {
+        slot = (slot + 1) & brickMask;
+    }
+    bricks[slot].vacant = vacant;
+    bricks[slot].base[0] = base0;
+    bricks[slot].base[1] = base1;
+    bricks[slot].base[2] = base2;
+    bricks[slot].base[3] = base3;
 }
 
 int gridFor(int64_t n) { return static_cast<int>((n + 255) / 256); }
@@ -2928,36 +2951,57 @@ hipError_t sortKeyPairs(void* scratch, size_t* scratchBytes, const unsigned long
                                               static_cast<int>(n), 0, 64, stream);
 }
 
-void launchCountRuns(const unsigned long long* sortedKeys, uint64_t n, unsigned long long* runs, hipStream_t stream)
+void launchCountRuns(const unsigned long long* sortedKeys, uint64_t n, int shift, unsigned long long* runs, hipStream_t stream)
 {
     if (n == 0) return;
     hipLaunchKernelGGL(countRunsKernel, dim3(gridFor(static_cast<int64_t>((n + kRunsPerThread - 1) / kRunsPerThread))), dim3(256),
-                       0, stream, sortedKeys, n, runs);
+                       0, stream, sortedKeys, n, shift, runs);
 }
 
-void launchProbeTable(const unsigned long long* sortedKeys, const uint32_t* sortedOrder, const double* points, uint64_t n,
-                      int64_t* slotKey, uint32_t* slotStart, uint32_t* slotCount, PackedCell* packedCells,
-                      uint64_t slotMask, double* groupedPoints, hipStream_t stream)
+void launchRunHeads(const unsigned long long* sortedKeys, uint64_t n, int shift, uint32_t* heads, hipStream_t stream)
 {
     if (n == 0) return;
-    hipLaunchKernelGGL(probeTableKernel, dim3(gridFor(static_cast<int64_t>(n))), dim3(256), 0, stream, sortedKeys, sortedOrder,
-                       points, n, slotKey, slotStart, slotCount, packedCells, slotMask, groupedPoints);
+    hipLaunchKernelGGL(runHeadsKernel, dim3(gridFor(static_cast<int64_t>(n))), dim3(256), 0, stream, sortedKeys, n, shift, heads);
 }
 
-void launchNeighbourKeys(const unsigned long long* sortedKeys, uint64_t n, unsigned long long* outKeys,
-                         uint32_t* outBits, unsigned long long* cursor, hipStream_t stream)
+void launchDenseCells(const unsigned long long* sortedKeys, const uint32_t* sortedOrder, const uint64_t* ordinal,
+                      const double* points, uint64_t n, DenseCell* cells, double* groupedPoints, hipStream_t stream)
 {
     if (n == 0) return;
-    hipLaunchKernelGGL(neighbourKeysKernel, dim3(gridFor(static_cast<int64_t>(n))), dim3(256), 0, stream, sortedKeys, n, outKeys,
-                       outBits, cursor);
+    hipLaunchKernelGGL(denseCellsKernel, dim3(gridFor(static_cast<int64_t>(n))), dim3(256), 0, stream, sortedKeys, sortedOrder,
+                       ordinal, points, n, cells, groupedPoints);
 }
 
-void launchNeighbourTable(const unsigned long long* sortedKeys, const uint32_t* sortedBits, uint64_t n,
-                          NearEntry* nearEntries, uint64_t nearMask, hipStream_t stream)
+void launchCellGroups(const unsigned long long* sortedKeys, const uint64_t* cellOrdinal, const uint64_t* groupOrdinal, uint64_t n,
+                      unsigned long long* groupKey, uint32_t* groupOwn, uint32_t* groupFirst, hipStream_t stream)
 {
     if (n == 0) return;
-    hipLaunchKernelGGL(neighbourTableKernel, dim3(gridFor(static_cast<int64_t>(n))), dim3(256), 0, stream, sortedKeys, sortedBits,
-                       n, nearEntries, nearMask);
+    hipLaunchKernelGGL(cellGroupsKernel, dim3(gridFor(static_cast<int64_t>(n))), dim3(256), 0, stream, sortedKeys, cellOrdinal,
+                       groupOrdinal, n, groupKey, groupOwn, groupFirst);
+}
+
+void launchBrickLists(const unsigned long long* groupKey, uint64_t groups, unsigned long long* listKeys, uint32_t* listEntries,
+                      hipStream_t stream)
+{
+    if (groups == 0) return;
+    hipLaunchKernelGGL(brickListsKernel, dim3(gridFor(static_cast<int64_t>(8 * groups))), dim3(256), 0, stream, groupKey, groups,
+                       listKeys, listEntries);
+}
+
+hipError_t mergeKeyPairs(void* scratch, size_t* scratchBytes, const unsigned long long* keysA, const uint32_t* valuesA, uint64_t nA,
+                         const unsigned long long* keysB, const uint32_t* valuesB, uint64_t nB, unsigned long long* keysOut,
+                         uint32_t* valuesOut, hipStream_t stream)
+{
+    return hipcub::DeviceMerge::MergePairs(scratch, *scratchBytes, keysA, valuesA, static_cast<int>(nA), keysB, valuesB,
+                                           static_cast<int>(nB), keysOut, valuesOut, ::rocprim::less<unsigned long long>(), stream);
+}
+
+void launchBricks(const unsigned long long* mergedKeys, const uint32_t* mergedEntries, uint64_t total, const uint32_t* groupOwn,
+                  const uint32_t* groupFirst, ProbeBrick* bricks, uint64_t brickMask, hipStream_t stream)
+{
+    if (total == 0) return;
+    hipLaunchKernelGGL(bricksKernel, dim3(gridFor(static_cast<int64_t>(total))), dim3(256), 0, stream, mergedKeys, mergedEntries,
+                       total, groupOwn, groupFirst, bricks, brickMask);
 }
 
 void launchProbeTest(const ProbeView& probes, int64_t n, const double* points, uint8_t* out, hipStream_t stream)

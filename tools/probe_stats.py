@@ -15,3 +15,7 @@ for name in sys.argv[1:]:
     u, c = np.unique(key, return_counts=True)
     print(name, "probes", p.shape[0], "keep radius", cell, "cells", u.shape[0], "probes/cell mean %.1f median %d p90 %d max %d" % (
         c.mean(), np.median(c), np.percentile(c, 90), c.max()), flush=True)
+    near = np.unique((u[:, None] + np.array([(dx << 42) + (dy << 21) + dz for dx in (-1, 0, 1) for dy in (-1, 0, 1) for dz in (-1, 0, 1)], dtype=np.int64)[None, :]).ravel())
+    zrun = np.unique((u[:, None] + np.array([-1, 0, 1], dtype=np.int64)[None, :]).ravel())
+    print(name, "cells in the 27-neighbourhoods", near.shape[0], "(%.1f per occupied cell);" % (near.shape[0] / u.shape[0]),
+          "in the z-neighbourhoods", zrun.shape[0], "; extent of the cell box", (k.max(axis=0) - k.min(axis=0) + 1).tolist(), flush=True)
