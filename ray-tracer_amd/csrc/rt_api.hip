@@ -198,6 +198,7 @@ struct rt_tracer
     DeviceArray<double> triRec, triNrm;
     DeviceArray<int32_t> triId, triOwner;
     DeviceArray<rtd::Material> materials;
+    bool hasDielectric = false;
     DeviceArray<rtd::Light> lights;
     DeviceArray<rtd::Camera> cameras;
     DeviceArray<rt_animation> animations;
@@ -294,6 +295,7 @@ struct rt_tracer
         DeviceArray<uint32_t> counts;
         DeviceArray<uint64_t> offsets;
         DeviceArray<rtd::GatherPoint> devicePoints;
+        DeviceArray<rtd::GatherPoint> slots;    // a record per pixel, before they are moved together (one-pass form)
         uint64_t total = 0;                     // records on the device
         std::vector<rtd::GatherPoint> points;   // host copy, made when first asked for
         bool hostCopied = false;
@@ -993,6 +995,11 @@ void buildScene(rt_tracer* t, const rt_scene* scene)
     t->triId.upload(triId);
     t->triOwner.upload(triOwner);
     t->materials.upload(materials);
+    t->hasDielectric = false;
+    for (const rtd::Material& m : materials)
+    {
+        if (m.type == RT_MATERIAL_DIELECTRIC) t->hasDielectric = true;
+    }
     t->lights.upload(lights);
     t->cameras.upload(t->cameraHost);
     t->scalars.allocate(4);
@@ -1225,7 +1232,20 @@ rt_tracer::GatherCache& ensureGatherPoints(rt_tracer* tracer, int32_t camera)
     const size_t span = beginSetupSpan(tracer, 0);
     cache.counts.zero(tracer->stream);
     stats.zero(tracer->stream);
-    rtd::launchGatherCount(tracer->view, camera, stride, pixels, cache.counts.ptr, stats.ptr, tracer->stream);
+    // one record a pixel at most (collectPixel's sample loops run once): one pass of casts does
+    const bool lensSamples = cam.projection == RT_PROJECTION_REALLENS && cam.apertureRadius > 0.0;
+    const bool shutterSamples = tracer->view.shutterSpan > 0.0f && tracer->view.cameraTimeSamples > 1;
+    const bool onePass = !lensSamples && !shutterSamples && !tracer->hasDielectric;
+    if (onePass)
+    {
+        cache.slots.reserve(static_cast<size_t>(std::max<int64_t>(pixels, 1)));
+        rtd::launchGatherCollect(tracer->view, camera, stride, pixels, cache.counts.ptr, stats.ptr, cache.slots.ptr,
+                                 tracer->stream);
+    }
+    else
+    {
+        rtd::launchGatherCount(tracer->view, camera, stride, pixels, cache.counts.ptr, stats.ptr, tracer->stream);
+    }
     check(hipGetLastError(), "gather count launch");
     // offsets of every pixel's records: exclusive scan of the counts, on the device
     cache.offsets.reserve(static_cast<size_t>(pixels));
@@ -1256,7 +1276,13 @@ rt_tracer::GatherCache& ensureGatherPoints(rt_tracer* tracer, int32_t camera)
     cache.points.clear();
     cache.hostCopied = false;
     cache.devicePoints.reserve(static_cast<size_t>(std::max<uint64_t>(total, 1)));
-    if (total > 0)
+    if (total > 0 && onePass)
+    {
+        rtd::launchGatherCompact(cache.slots.ptr, cache.counts.ptr, cache.offsets.ptr, pixels, cache.devicePoints.ptr,
+                                 tracer->stream);
+        check(hipGetLastError(), "gather compact launch");
+    }
+    else if (total > 0)
     {
         rtd::launchGatherWrite(tracer->view, camera, stride, pixels, cache.counts.ptr, cache.offsets.ptr,
                                cache.devicePoints.ptr, tracer->stream);

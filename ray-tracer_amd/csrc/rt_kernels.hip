@@ -1250,6 +1250,47 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
     });
 }
 
+// Where a pixel has one sample at most (no shutter samples, no lens samples, no dielectric in the scene:
+// collectPixel's loops run once) a single pass of casts does: every pixel's record goes to the pixel's own
+// slot, and once the counts are scanned the records are moved to their places (no second cast).
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void gatherCollectKernel(const SceneView s, int32_t camera, int32_t stride, uint32_t* counts,
+                                    unsigned long long* stats, GatherPoint* slots)
+{
+    const Camera& cam = s.cameras[camera];
+    const int32_t gw = (cam.width + stride - 1) / stride, gh = (cam.height + stride - 1) / stride;
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    unsigned long long local[3] = {0, 0, 0};
+    if (i < static_cast<int64_t>(gw) * gh)
+    {
+        const int32_t px = static_cast<int32_t>(i % gw) * stride, py = static_cast<int32_t>(i / gw) * stride;
+        GatherPoint* dst = slots + i;
+        counts[i] = static_cast<uint32_t>(collectPixel(s, camera, px, py, local, [&](const GatherPoint& gp, int k) {
+            if (k == 0) *dst = gp;  // sampleWeight is 1 / 1 already
+        }));
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+    {
+        const unsigned long long total = waveSum(local[k]);
+        if ((threadIdx.x & 63) == 0 && total != 0)
+        {
+            atomicAdd(stats + k, total);
+        }
+    }
+}
+
+// a record is 30 words: a thread per word
+__global__ void gatherCompactKernel(const GatherPoint* slots, const uint32_t* counts, const uint64_t* offsets, int64_t pixels,
+                                    GatherPoint* out)
+{
+    constexpr int kWords = static_cast<int>(sizeof(GatherPoint) / sizeof(uint32_t));
+    const int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const int64_t i = t / kWords;
+    if (i >= pixels || counts[i] == 0) return;
+    const int word = static_cast<int>(t - i * kWords);
+    reinterpret_cast<uint32_t*>(out + offsets[i])[word] = reinterpret_cast<const uint32_t*>(slots + i)[word];
+}
+
 // ProbeIndex::anyWithinKeepRadius for host-supplied points (emitter deposits,
 // reference src/ProbeGather.cpp:536-541).
 __global__ void probeTestKernel(const ProbeView pv, int64_t n, const double* points, uint8_t* out)
@@ -2755,6 +2796,23 @@ void launchGatherWrite(const SceneView& scene, int32_t camera, int32_t stride, i
     if (pixels <= 0) return;
     hipLaunchKernelGGL(gatherWriteKernel, dim3(static_cast<uint32_t>((pixels + 63) / 64)), dim3(64), stackBytes(scene, 64), stream, scene,
                        camera, stride, counts, offsets, out);
+}
+
+void launchGatherCollect(const SceneView& scene, int32_t camera, int32_t stride, int64_t pixels, uint32_t* counts,
+                         unsigned long long* stats, GatherPoint* slots, hipStream_t stream)
+{
+    if (pixels <= 0) return;
+    hipLaunchKernelGGL(gatherCollectKernel, dim3(static_cast<uint32_t>((pixels + 63) / 64)), dim3(64), stackBytes(scene, 64), stream,
+                       scene, camera, stride, counts, stats, slots);
+}
+
+void launchGatherCompact(const GatherPoint* slots, const uint32_t* counts, const uint64_t* offsets, int64_t pixels, GatherPoint* out,
+                         hipStream_t stream)
+{
+    if (pixels <= 0) return;
+    const int64_t threads = pixels * static_cast<int64_t>(sizeof(GatherPoint) / sizeof(uint32_t));
+    hipLaunchKernelGGL(gatherCompactKernel, dim3(static_cast<uint32_t>((threads + 255) / 256)), dim3(256), 0, stream, slots, counts,
+                       offsets, pixels, out);
 }
 
 hipError_t buildCellDirectory(void* scratch, size_t* scratchBytes, const unsigned long long* sortedKeys, uint64_t indexed,
