@@ -124,139 +124,105 @@ RT_DEV unsigned long long orderedProbeCell(int64_t kx, int64_t ky, int64_t kz)
     return ((x >> 1) << 43) | ((y >> 1) << 23) | (z << 2) | ((y & 1) << 1) | (x & 1);
 }
 
-// The keep test through the brick table, as one loop with ONE load per trip.  Every lane walks its own
-// chain of dependent reads (brick entry -> cell -> further probes of the cell -> next cell ...), and a
-// wave pays a memory round trip per trip of whichever loop it is in; nested per-table loops cost the sum
-// of the longest chain of each loop over the wave, this loop costs the longest total of one lane.  All
-// three arrays are read with the same 32-byte load (a brick entry, a cell with its first probe, or a
-// probe position and what follows it).  The brick entry is the only hashed lookup: it tells which of the
-// 27 cells around p hold probes and where each of them lies in the dense cell array.
-// Order: the deposit's own cell first (on a surface the camera sees it usually holds a probe in
-// reach), then the other occupied cells (their order made no measurable difference), skipping
-// those whose box lies farther from p than the
-// keep radius (gaps in cell units; the bound carries 1e-6 of slack against the rounding of the
-// cell index).
+// The keep test through the brick table.  Every lane walks its own chain of dependent reads (brick entry
+// -> cell -> further probes of the cell -> next cell ...), and a wave pays a memory round trip and the
+// instructions of a trip for every trip of its slowest lane, so a trip is kept lean: the brick entry is
+// the only hashed lookup — it tells which of the 27 cells around p hold probes and where each of them
+// lies in the dense cell array — and which of those cells are worth a look is settled once, before the
+// walk (those whose box lies farther from p than the keep radius are not: gaps in cell units, in single
+// precision with 1e-5 of slack, the bound only has to be safe), as a mask in the brick's own bit
+// positions.  The walk then takes the deposit's own cell first (on a surface the camera sees it usually
+// holds a probe in reach) and the others in the order of their bits.
 RT_DEV bool anyProbeInNeighbourhood(const ProbeView& pv, const Vec& p, double r2, int64_t cx, int64_t cy, int64_t cz)
 {
     typedef uint32_t Uint4At8 __attribute__((ext_vector_type(4), aligned(8)));
-    constexpr uint32_t kCentreBit = 1u << 13;
-    enum { kBrick = 0, kCell = 1, kPoints = 2, kFinished = 3 };
-    const double fx = p.x * pv.invCellSize - static_cast<double>(cx);
-    const double fy = p.y * pv.invCellSize - static_cast<double>(cy);
-    const double fz = p.z * pv.invCellSize - static_cast<double>(cz);
-    const double reach2 = r2 * pv.invCellSize * pv.invCellSize * (1.0 + 1e-6);
     // the brick that holds the 27 cells around (cx, cy, cz), and where in it the first of them lies (0 or 1)
     const int64_t mx = (cx - 1) >> 1, my = (cy - 1) >> 1, mz = (cz - 1) >> 1;
     const int ox = static_cast<int>(cx - 1 - 2 * mx), oy = static_cast<int>(cy - 1 - 2 * my), oz = static_cast<int>(cz - 1 - 2 * mz);
-
-    int phase = kBrick;
-    bool found = false;
-    uint32_t bits = 0;       // occupied neighbour cells not visited yet
-    uint32_t remaining = 0;  // probes of the current cell not tested yet
-    unsigned long long occupied = 0;
-    uint32_t base0 = 0, base1 = 0, base2 = 0, base3 = 0;
     const unsigned long long key = packProbeCell(mx, my, mz);
     uint64_t slot = cellHash(mx, my, mz) & pv.brickMask;
-    const char* address = reinterpret_cast<const char*>(pv.bricks + slot);
-    while (phase != kFinished)
+    unsigned long long occupied = 0;
+    uint32_t base0 = 0, base1 = 0, base2 = 0, base3 = 0;
+    while (true)
     {
         RT_DIAG_TRIP(12);
+        const char* address = reinterpret_cast<const char*>(pv.bricks + slot);
         const Uint4At8 head = *reinterpret_cast<const Uint4At8*>(address);
         const Uint4At8 mid = *reinterpret_cast<const Uint4At8*>(address + 16);
         const unsigned long long first = (static_cast<unsigned long long>(head.y) << 32) | head.x;
-        const unsigned long long second = (static_cast<unsigned long long>(head.w) << 32) | head.z;
-        const unsigned long long third = (static_cast<unsigned long long>(mid.y) << 32) | mid.x;
-        bool nextCell = false;
-        if (phase == kBrick)
+        if (first == key)
         {
-            if (first == key)
-            {
-                occupied = ~second;
-                base0 = mid.x;
-                base1 = mid.y;
-                base2 = mid.z;
-                base3 = mid.w;
-                // the 3 x 3 x 3 window of the brick's bits around the cell: bit iz * 9 + iy * 3 + ix
-#pragma unroll
-                for (int iz = 0; iz < 3; ++iz)
-                {
-#pragma unroll
-                    for (int iy = 0; iy < 3; ++iy)
-                    {
-                        const uint32_t row = static_cast<uint32_t>(occupied >> (ox + 4 * (oy + iy) + 16 * (oz + iz))) & 7u;
-                        bits |= row << (iz * 9 + iy * 3);
-                    }
-                }
-                nextCell = true;
-            }
-            else if (first == kEmptyKey)
-            {
-                phase = kFinished;  // no occupied cell around p
-            }
-            else
-            {
-                slot = (slot + 1) & pv.brickMask;
-                address = reinterpret_cast<const char*>(pv.bricks + slot);
-            }
+            occupied = ~((static_cast<unsigned long long>(head.w) << 32) | head.z);
+            base0 = mid.x;
+            base1 = mid.y;
+            base2 = mid.z;
+            base3 = mid.w;
+            break;
         }
-        else
+        if (first == kEmptyKey)
         {
-            if (phase == kCell)
-            {
-                remaining = mid.w;
-            }
-            const double ddx = __builtin_bit_cast(double, first) - p.x;
-            const double ddy = __builtin_bit_cast(double, second) - p.y;
-            const double ddz = __builtin_bit_cast(double, third) - p.z;
-            if (ddx * ddx + ddy * ddy + ddz * ddz <= r2)
-            {
-                found = true;
-                phase = kFinished;
-            }
-            else if (--remaining == 0)
-            {
-                nextCell = true;
-            }
-            else if (phase == kCell)
-            {
-                // the cell's entry carries its first probe; the others follow it in `points`
-                phase = kPoints;
-                address = reinterpret_cast<const char*>(pv.points + 3ull * (mid.z + 1u));
-            }
-            else
-            {
-                address += 3 * sizeof(double);
-            }
+            return false;  // no occupied cell around p
         }
-        if (nextCell)
+        slot = (slot + 1) & pv.brickMask;
+    }
+    // the cells of the neighbourhood in reach of p, as bits of the brick
+    const float fx = static_cast<float>(p.x * pv.invCellSize - static_cast<double>(cx));
+    const float fy = static_cast<float>(p.y * pv.invCellSize - static_cast<double>(cy));
+    const float fz = static_cast<float>(p.z * pv.invCellSize - static_cast<double>(cz));
+    const float reach2 = static_cast<float>(r2 * pv.invCellSize * pv.invCellSize) + 1e-5f;
+    const float lowX = fx * fx, highX = (1.0f - fx) * (1.0f - fx);
+    const float gapY[3] = {fy * fy, 0.0f, (1.0f - fy) * (1.0f - fy)};
+    const float gapZ[3] = {fz * fz, 0.0f, (1.0f - fz) * (1.0f - fz)};
+    unsigned long long worth = 0;
+#pragma unroll
+    for (int iz = 0; iz < 3; ++iz)
+    {
+#pragma unroll
+        for (int iy = 0; iy < 3; ++iy)
         {
-            phase = kFinished;
-            while (bits != 0)
+            const float budget = reach2 - (gapY[iy] + gapZ[iz]);
+            const uint32_t row = (lowX <= budget ? 1u : 0u) | (0.0f <= budget ? 2u : 0u) | (highX <= budget ? 4u : 0u);
+            worth |= static_cast<unsigned long long>(row) << (ox + 4 * (oy + iy) + 16 * (oz + iz));
+        }
+    }
+    unsigned long long candidates = occupied & worth;
+    const int centre = (ox + 1) + 4 * (oy + 1) + 16 * (oz + 1);
+    while (candidates != 0)
+    {
+        RT_DIAG_TRIP(12);
+        const int bit = ((candidates >> centre) & 1ull) != 0 ? centre : __builtin_ctzll(candidates);
+        candidates &= ~(1ull << bit);
+        // the cell's place: its column's base + the occupied cells of the column below its bit
+        // (column (x >> 1) + 2 (y >> 1): bits 1 and 3 of the cell's bit number)
+        const unsigned long long inColumn = 0x0033003300330033ull << (bit & 10);
+        const unsigned long long below = (1ull << bit) - 1ull;
+        const int column = ((bit >> 1) & 1) + ((bit >> 2) & 2);
+        const uint32_t base = column == 0 ? base0 : (column == 1 ? base1 : (column == 2 ? base2 : base3));
+        const char* address =
+            reinterpret_cast<const char*>(pv.cells + (base + static_cast<uint32_t>(__builtin_popcountll(occupied & inColumn & below))));
+        const Uint4At8 head = *reinterpret_cast<const Uint4At8*>(address);
+        const Uint4At8 mid = *reinterpret_cast<const Uint4At8*>(address + 16);
+        const double qx = __builtin_bit_cast(double, (static_cast<unsigned long long>(head.y) << 32) | head.x);
+        const double qy = __builtin_bit_cast(double, (static_cast<unsigned long long>(head.w) << 32) | head.z);
+        const double qz = __builtin_bit_cast(double, (static_cast<unsigned long long>(mid.y) << 32) | mid.x);
+        const double ddx = qx - p.x, ddy = qy - p.y, ddz = qz - p.z;
+        if (ddx * ddx + ddy * ddy + ddz * ddz <= r2)
+        {
+            return true;
+        }
+        // the further probes of a cell that holds several (few do) follow its first in `points`
+        const double* pt = pv.points + 3ull * mid.z;
+        for (uint32_t i = 1; i < mid.w; ++i)
+        {
+            RT_DIAG_TRIP(12);
+            const double ex = pt[3 * i] - p.x, ey = pt[3 * i + 1] - p.y, ez = pt[3 * i + 2] - p.z;
+            if (ex * ex + ey * ey + ez * ez <= r2)
             {
-                const int b = (bits & kCentreBit) != 0 ? 13 : __builtin_ctz(bits);
-                bits &= ~(1u << b);
-                const int iz = b / 9, iy = (b / 3) % 3, ix = b % 3;
-                const double gx = ix == 0 ? fx : (ix == 1 ? 0.0 : 1.0 - fx);
-                const double gy = iy == 0 ? fy : (iy == 1 ? 0.0 : 1.0 - fy);
-                const double gz = iz == 0 ? fz : (iz == 1 ? 0.0 : 1.0 - fz);
-                if (gx * gx + gy * gy + gz * gz > reach2)
-                {
-                    continue;
-                }
-                // the cell's place: its column's base + the occupied cells of the column below its bit
-                const int bx = ox + ix, by = oy + iy, bz = oz + iz;
-                const int column = (bx >> 1) + 2 * (by >> 1);
-                const unsigned long long below = (1ull << (bx + 4 * by + 16 * bz)) - 1ull;
-                const unsigned long long inColumn = 0x0033003300330033ull << (2 * (bx >> 1) + 8 * (by >> 1));
-                const uint32_t base = column == 0 ? base0 : (column == 1 ? base1 : (column == 2 ? base2 : base3));
-                const uint32_t place = base + static_cast<uint32_t>(__builtin_popcountll(occupied & inColumn & below));
-                address = reinterpret_cast<const char*>(pv.cells + place);
-                phase = kCell;
-                break;
+                return true;
             }
         }
     }
-    return found;
+    return false;
 }
 
 // ProbeIndex::anyWithin, reference src/ProbeIndex.cpp:27-68.  The result is a pure
@@ -884,7 +850,9 @@ __global__ __launch_bounds__(kTraceThreads) __attribute__((amdgpu_waves_per_eu((
                     if (!delta)
                     {
                         RT_DIAG_TRIP(10);
+                        RT_DIAG_TIC(keepStart);
                         keep = anyProbeWithin(a.probes, hit.position);
+                        RT_DIAG_TOC(keepStart, 11);
                         tally(lc, kTallyKept, keep);
                         tally(lc, kTallyCulled, !keep);
                     }
@@ -2615,8 +2583,8 @@ void printDiagnostics()
     if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_rtDiag), sizeof(host)) != hipSuccess) return;
 #if RT_DIAG == 2
     const char* names[] = {"kernel",       "casts",         "node loops",     "triangle loops", "refill",      "deposit",
-                           "scatter",      "cast: box",     "cast: pose",     "cast: normal",   "cast: world"};
-    for (int k = 0; k < 11; ++k)
+                           "scatter",      "cast: box",     "cast: pose",     "cast: normal",   "cast: world", "deposit: keep"};
+    for (int k = 0; k < 12; ++k)
     {
         fprintf(stderr, "[rt diag] wave cycles  %-15s %16llu  (%.1f %% of the kernel)\n", names[k], host[k],
                 host[0] ? 100.0 * static_cast<double>(host[k]) / static_cast<double>(host[0]) : 0.0);
