@@ -295,7 +295,10 @@ struct rt_tracer
         DeviceArray<uint32_t> counts;
         DeviceArray<uint64_t> offsets;
         DeviceArray<rtd::GatherPoint> devicePoints;
-        DeviceArray<rtd::GatherPoint> slots;    // a record per pixel, before they are moved together (one-pass form)
+        DeviceArray<rtd::GatherPoint> slots;    // a record per pixel (one-pass form)
+        // one-pass form: the records lie in `slots` at their pixels' places; devicePoints holds them together
+        // only once somebody wants them so (gatheredTogether)
+        bool byPixel = false, together = false;
         uint64_t total = 0;                     // records on the device
         std::vector<rtd::GatherPoint> points;   // host copy, made when first asked for
         bool hostCopied = false;
@@ -1275,14 +1278,10 @@ rt_tracer::GatherCache& ensureGatherPoints(rt_tracer* tracer, int32_t camera)
     cache.total = total;
     cache.points.clear();
     cache.hostCopied = false;
-    cache.devicePoints.reserve(static_cast<size_t>(std::max<uint64_t>(total, 1)));
-    if (total > 0 && onePass)
-    {
-        rtd::launchGatherCompact(cache.slots.ptr, cache.counts.ptr, cache.offsets.ptr, pixels, cache.devicePoints.ptr,
-                                 tracer->stream);
-        check(hipGetLastError(), "gather compact launch");
-    }
-    else if (total > 0)
+    if (!onePass) cache.devicePoints.reserve(static_cast<size_t>(std::max<uint64_t>(total, 1)));
+    cache.byPixel = onePass;
+    cache.together = !onePass;
+    if (total > 0 && !onePass)
     {
         rtd::launchGatherWrite(tracer->view, camera, stride, pixels, cache.counts.ptr, cache.offsets.ptr,
                                cache.devicePoints.ptr, tracer->stream);
@@ -1300,6 +1299,15 @@ rt_tracer::GatherCache& ensureGatherPoints(rt_tracer* tracer, int32_t camera)
 // The probe pass's records on the host (copied once, when a caller wants to read them).
 const std::vector<rtd::GatherPoint>& hostGatherPoints(rt_tracer* tracer, rt_tracer::GatherCache& cache)
 {
+    if (!cache.together)
+    {
+        // the one-pass form keeps the records at their pixels: moved together when they are first asked for
+        cache.devicePoints.reserve(static_cast<size_t>(std::max<uint64_t>(cache.total, 1)));
+        rtd::launchGatherCompact(cache.slots.ptr, cache.counts.ptr, cache.offsets.ptr, cache.pixels, cache.devicePoints.ptr,
+                                 tracer->stream);
+        check(hipGetLastError(), "gather compact launch");
+        cache.together = true;
+    }
     if (!cache.hostCopied)
     {
         cache.points.assign(static_cast<size_t>(cache.total), rtd::GatherPoint{});
@@ -1933,7 +1941,15 @@ int32_t rt_set_probes_from_cameras(rt_tracer* tracer, double cell_size, double k
         uint64_t at = 0;
         for (rt_tracer::GatherCache* cache : caches)
         {
-            rtd::launchProbePositions(cache->devicePoints.ptr, cache->total, positions.ptr + 3 * at, tracer->stream);
+            if (cache->byPixel)
+            {
+                rtd::launchPixelProbePositions(cache->slots.ptr, cache->counts.ptr, cache->offsets.ptr, cache->pixels,
+                                               positions.ptr + 3 * at, tracer->stream);
+            }
+            else
+            {
+                rtd::launchProbePositions(cache->devicePoints.ptr, cache->total, positions.ptr + 3 * at, tracer->stream);
+            }
             at += cache->total;
         }
         check(hipGetLastError(), "probe positions launch");
@@ -3143,8 +3159,8 @@ int32_t rt_gather(rt_tracer* tracer, int32_t camera, double gather_cell_size, do
         args.camera = camera;
         args.pixels = cache.pixels;
         args.counts = cache.counts.ptr;
-        args.offsets = cache.offsets.ptr;
-        args.points = cache.devicePoints.ptr;
+        args.offsets = cache.byPixel ? nullptr : cache.offsets.ptr;
+        args.points = cache.byPixel ? cache.slots.ptr : cache.devicePoints.ptr;
         args.stats = stats.ptr;
         args.directoryKind = indexed > 0 ? g.directoryKind : rtd::kDirectoryNone;
         args.cellStart = args.directoryKind != rtd::kDirectoryNone ? g.cellStart.ptr : nullptr;

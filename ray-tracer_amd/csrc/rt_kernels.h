@@ -226,7 +226,7 @@ struct GatherArgs
     int32_t camera;
     int64_t pixels;                     // sampled pixels of the camera's probe pass
     const uint32_t* counts;             // gather points per sampled pixel
-    const uint64_t* offsets;            // first gather point of each sampled pixel
+    const uint64_t* offsets;            // first gather point of each sampled pixel; null: pixel i's one record lies at points[i]
     const GatherPoint* points;
     unsigned long long* stats;          // [0] contributions added, [1] deposits summed
     // Directory of the key list over the box of cells that hold records.  kDirectoryCells:
@@ -301,6 +301,8 @@ void launchEmitterCount(const EmitterGrid& grid, unsigned long long* count, hipS
 void launchEmitterDeposit(const EmitterGrid& grid, const ProbeView& probes, const StoreView& store,
                           unsigned long long* kept, hipStream_t stream);
 void launchProbePositions(const GatherPoint* points, uint64_t n, double* positions, hipStream_t stream);
+void launchPixelProbePositions(const GatherPoint* slots, const uint32_t* counts, const uint64_t* offsets, int64_t pixels,
+                               double* positions, hipStream_t stream);
 // stable ascending sort of (keys, order) pairs of any length below 2^31
 hipError_t sortKeyPairs(void* scratch, size_t* scratchBytes, const unsigned long long* keysIn, unsigned long long* keysOut,
                         const uint32_t* orderIn, uint32_t* orderOut, uint64_t n, hipStream_t stream);

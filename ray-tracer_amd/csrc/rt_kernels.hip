@@ -1801,7 +1801,7 @@ __global__ __launch_bounds__(kGatherThreads) void gatherKernel(const GatherArgs 
     if (i < a.pixels && a.counts[i] != 0)
     {
         const Camera& cam = a.scene.cameras[a.camera];
-        const GatherPoint* points = a.points + a.offsets[i];
+        const GatherPoint* points = a.points + (a.offsets ? a.offsets[i] : static_cast<uint64_t>(i));
         Color acc{0.0f, 0.0f, 0.0f};
         for (uint32_t k = 0; k < a.counts[i]; ++k)
         {
@@ -2234,7 +2234,7 @@ __global__ __launch_bounds__(256) void gatherGroupKernel(const GatherArgs a)
             continue;
         }
         const Camera& cam = a.scene.cameras[a.camera];
-        const GatherPoint* points = a.points + a.offsets[i];
+        const GatherPoint* points = a.points + (a.offsets ? a.offsets[i] : static_cast<uint64_t>(i));
         Color acc{0.0f, 0.0f, 0.0f};
         unsigned long long addedHere = 0;
         for (uint32_t k = 0; k < a.counts[i]; ++k)
@@ -2295,7 +2295,7 @@ __global__ __launch_bounds__(64 * W) void gatherBlockKernel(const GatherArgs a)
             continue;  // (the same for the whole block)
         }
         const Camera& cam = a.scene.cameras[a.camera];
-        const GatherPoint* points = a.points + a.offsets[i];
+        const GatherPoint* points = a.points + (a.offsets ? a.offsets[i] : static_cast<uint64_t>(i));
         Color acc{0.0f, 0.0f, 0.0f};
         unsigned long long addedHere = 0;
         for (uint32_t k = 0; k < a.counts[i]; ++k)
@@ -2394,6 +2394,18 @@ __global__ void emitterDepositKernel(const EmitterGrid g, const ProbeView probes
 }
 
 // positions of a camera's gather points, 3 doubles each: the probes of the keep test
+// the same from records that lie at their pixels' places (counts[i] is 0 or 1), written together
+__global__ void pixelProbePositionsKernel(const GatherPoint* slots, const uint32_t* counts, const uint64_t* offsets, int64_t pixels,
+                                          double* positions)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= pixels || counts[i] == 0) return;
+    double* out = positions + 3 * offsets[i];
+    out[0] = slots[i].position[0];
+    out[1] = slots[i].position[1];
+    out[2] = slots[i].position[2];
+}
+
 __global__ void probePositionsKernel(const GatherPoint* points, uint64_t n, double* positions)
 {
     const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -2962,6 +2974,14 @@ void launchProbePositions(const GatherPoint* points, uint64_t n, double* positio
 {
     if (n == 0) return;
     hipLaunchKernelGGL(probePositionsKernel, dim3(gridFor(static_cast<int64_t>(n))), dim3(256), 0, stream, points, n, positions);
+}
+
+void launchPixelProbePositions(const GatherPoint* slots, const uint32_t* counts, const uint64_t* offsets, int64_t pixels,
+                               double* positions, hipStream_t stream)
+{
+    if (pixels <= 0) return;
+    hipLaunchKernelGGL(pixelProbePositionsKernel, dim3(gridFor(pixels)), dim3(256), 0, stream, slots, counts, offsets, pixels,
+                       positions);
 }
 
 void launchProbeKeys(const ProbeBuild& b, uint32_t* unpackable, hipStream_t stream)
