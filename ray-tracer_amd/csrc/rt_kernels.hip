@@ -210,13 +210,30 @@ RT_DEV bool anyProbeInNeighbourhood(const ProbeView& pv, const Vec& p, double r2
         {
             return true;
         }
-        // the further probes of a cell that holds several (few do) follow its first in `points`
+        // the further probes of a cell that holds several follow its first in `points`: four a trip (a lane
+        // that walks a crowded cell holds up its whole wave)
         const double* pt = pv.points + 3ull * mid.z;
-        for (uint32_t i = 1; i < mid.w; ++i)
+        constexpr uint32_t kTogether = 4;
+        for (uint32_t i = 1; i < mid.w; i += kTogether)
         {
             RT_DIAG_TRIP(12);
-            const double ex = pt[3 * i] - p.x, ey = pt[3 * i + 1] - p.y, ez = pt[3 * i + 2] - p.z;
-            if (ex * ex + ey * ey + ez * ez <= r2)
+            double q[kTogether][3];
+#pragma unroll
+            for (uint32_t k = 0; k < kTogether; ++k)
+            {
+                const double* at = pt + 3 * (i + k < mid.w ? i + k : i);
+                q[k][0] = at[0];
+                q[k][1] = at[1];
+                q[k][2] = at[2];
+            }
+            bool any = false;
+#pragma unroll
+            for (uint32_t k = 0; k < kTogether; ++k)
+            {
+                const double ex = q[k][0] - p.x, ey = q[k][1] - p.y, ez = q[k][2] - p.z;
+                any = any || ex * ex + ey * ey + ez * ez <= r2;
+            }
+            if (any)
             {
                 return true;
             }
