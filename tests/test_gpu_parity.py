@@ -637,6 +637,52 @@ def test_probe_keep_test_matches_store_decisions(rt, scene_opener):
     assert np.array_equal(tracer.probe_keep_test(points), got)
 
 
+@pytest.mark.parametrize("cell_over_keep", [1.0, 2.5])
+def test_keep_test_equals_the_scan_over_all_probes(rt, scene_opener, cell_over_keep):
+    """The keep test as the device index answers it (bricks of cells over a dense cell array, the cells
+    around a point picked by their distance from it) against the definition, reference
+    src/ProbeIndex.cpp:27-68: some probe lies within the keep radius, by the reference's expression in the
+    reference's operation order.  Probes on both sides of the origin, on cell borders, crowded into single
+    cells (walked several a trip), alone in their bricks; points at the probes, a keep radius away from them
+    to the last bit or two, across cell and brick borders, and far from every probe."""
+    scene, tracer, orc = _open(rt, scene_opener, SCENES["mixed"])
+    rng = np.random.default_rng(17)
+    keep = 0.75
+    cell = keep * cell_over_keep
+    sheet = np.stack([rng.uniform(-20, 20, 6000), rng.uniform(-20, 20, 6000), np.zeros(6000)], axis=1)
+    sheet[:, 2] = 0.3 * np.sin(sheet[:, 0]) + 0.05 * sheet[:, 1]          # a surface through many bricks
+    on_borders = np.round(rng.uniform(-8, 8, (500, 3)) / cell) * cell       # coordinates that are multiples of the cell
+    crowded = np.array([3.1, -2.2, 7.7]) * cell + rng.uniform(0, 1, (70, 3)) * cell * 0.999  # seventy probes in one cell
+    crowded2 = np.array([-5.0, 4.0, -6.0]) * cell + rng.uniform(0, 1, (5, 3)) * cell * 0.999
+    lonely = rng.uniform(-300, 300, (40, 3))
+    probes = np.concatenate([sheet, on_borders, crowded, crowded2, lonely])
+    rng.shuffle(probes)
+    tracer.set_probes(probes, cell, keep, 4096)
+
+    directions = rng.normal(size=(4000, 3))
+    directions /= np.linalg.norm(directions, axis=1)[:, None]
+    picked = probes[rng.integers(0, len(probes), 4000)]
+    points = np.concatenate([
+        probes[:3000],                                            # at a probe
+        picked + directions * keep,                               # a keep radius away, as closely as rounding lets
+        picked + directions * keep * (1 + 1e-15),
+        picked + directions * keep * (1 - 1e-15),
+        picked + directions * rng.uniform(0, 2.5, (4000, 1)) * keep,
+        crowded.mean(0) + directions[:500] * rng.uniform(0.5, 1.5, (500, 1)) * keep,
+        rng.uniform(-25, 25, (4000, 3)),
+        rng.uniform(-400, 400, (500, 3)),
+        np.array([[1e7, 0.0, 0.0], [-1e7, 3.0, 2.0], [0.0, 0.0, 2e6 * cell]]),   # beyond the cells that pack
+    ])
+    got = tracer.probe_keep_test(points)
+    want = np.zeros(len(points), dtype=bool)
+    for start in range(0, len(points), 512):
+        d = probes[None, :, :] - points[start:start + 512, None, :]
+        d2 = d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1] + d[..., 2] * d[..., 2]
+        want[start:start + 512] = (d2 <= keep * keep).any(1)
+    assert want[:3000].all() and 0.2 < want.mean() < 0.9
+    assert np.array_equal(got.astype(bool), want), np.nonzero(got.astype(bool) != want)[0][:10]
+
+
 GATHER_SCENES = {
     "mixed": {"scene": "tests/scenes/mixed.json", "photons_per_light": 2500},
     "mixed_tight": {"scene": "tests/scenes/mixed.json", "photons_per_light": 2500, "probe_keep_radius_scale": 2.0},
