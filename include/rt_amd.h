@@ -214,8 +214,9 @@ int32_t rt_read_timings(rt_tracer* tracer, float* sort_ms, float* trace_ms);
 /* Device time of the frame's camera-side set-up, which the reference's photonPassSeconds includes
  * (ProbeGather::collectGatherPoints and the ProbeIndex, reference src/Renderer.cpp:297-419): the probe pass
  * of the cameras collected so far (rt_collect_gather_points / rt_set_probes_from_cameras), the build of
- * the probe index by the last rt_set_probes* (cell keys, sort, table) and of its neighbour filter; 0 for
- * what has not run, or ran on the host (index and filter of probes whose cells do not pack).  From HIP
+ * the probe index by the last rt_set_probes* — the probes keyed by cell, sorted, and the dense array of
+ * cells (index_build_ms), then the table of the bricks of cells the keep test looks up (filter_build_ms) —;
+ * 0 for what has not run, or ran on the host (the index of probes whose cells do not pack).  From HIP
  * events on the tracer's stream; waits for the stream.  Any pointer may be NULL. */
 int32_t rt_read_setup_timings(rt_tracer* tracer, float* probe_pass_ms, float* index_build_ms, float* filter_build_ms);
 /* Forget the probe passes kept per camera (rt_collect_gather_points caches them): the next collect runs

@@ -326,7 +326,7 @@ struct rt_tracer
     uint64_t storeVersion = 1;  // bumped by everything that writes the store or its cursor
 
     // Device time of the frame's camera-side set-up, as pairs of events on the tracer's stream: [0] the probe
-    // pass of every camera, [1] the probe index (keys, sort, table), [2] its neighbour filter
+    // pass of every camera, [1] the probe index (keys, sort, dense cells), [2] its table of bricks
     struct TimedSpan
     {
         hipEvent_t begin = nullptr, end = nullptr;

@@ -244,7 +244,7 @@ RT_DEV bool anyProbeInNeighbourhood(const ProbeView& pv, const Vec& p, double r2
 
 // ProbeIndex::anyWithin, reference src/ProbeIndex.cpp:27-68.  The result is a pure
 // "exists", so the scan order is free; the squared-distance test is the reference's
-// expression.  With the neighbourhood filter one lookup tells which of the 27 cells
+// expression.  In the brick form of the grid one lookup tells which of the 27 cells
 // around p hold probes at all: a deposit far from every probe costs that one lookup.
 RT_DEV bool anyProbeWithin(const ProbeView& pv, const Vec& p)
 {
@@ -2410,8 +2410,8 @@ __global__ void emitterDepositKernel(const EmitterGrid g, const ProbeView probes
     if ((threadIdx.x & 63) == 0 && mine != 0) atomicAdd(kept, mine);
 }
 
-// positions of a camera's gather points, 3 doubles each: the probes of the keep test
-// the same from records that lie at their pixels' places (counts[i] is 0 or 1), written together
+// positions of a camera's gather points, 3 doubles each: the probes of the keep test — from records that lie
+// at their pixels' places (counts[i] is 0 or 1), written together, and from records that lie together
 __global__ void pixelProbePositionsKernel(const GatherPoint* slots, const uint32_t* counts, const uint64_t* offsets, int64_t pixels,
                                           double* positions)
 {

@@ -250,7 +250,7 @@ class Tracer:
         return float(sort_ms.value), float(trace_ms.value)
 
     def setup_timings(self):
-        """Device ms of the camera-side set-up so far: probe pass, probe index, neighbour filter."""
+        """Device ms of the camera-side set-up so far: probe pass, probe index (cells), its table of bricks."""
         a, b, c = C.c_float(), C.c_float(), C.c_float()
         _check(tracer_lib().rt_read_setup_timings(self._handle, C.byref(a), C.byref(b), C.byref(c)))
         return {"probe_pass": float(a.value), "index_build": float(b.value), "filter_build": float(c.value)}
