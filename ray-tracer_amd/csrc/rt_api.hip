@@ -296,6 +296,8 @@ struct rt_tracer
         DeviceArray<uint64_t> offsets;
         DeviceArray<rtd::GatherPoint> devicePoints;
         DeviceArray<rtd::GatherPoint> slots;    // a record per pixel (one-pass form)
+        DeviceArray<uint32_t> deferred;         // one-pass form: the pixels its second launch finishes
+        DeviceArray<unsigned long long> deferredCount;
         // one-pass form: the records lie in `slots` at their pixels' places; devicePoints holds them together
         // only once somebody wants them so (gatheredTogether)
         bool byPixel = false, together = false;
@@ -1242,8 +1244,11 @@ rt_tracer::GatherCache& ensureGatherPoints(rt_tracer* tracer, int32_t camera)
     if (onePass)
     {
         cache.slots.reserve(static_cast<size_t>(std::max<int64_t>(pixels, 1)));
+        cache.deferred.reserve(static_cast<size_t>(std::max<int64_t>(pixels, 1)));
+        cache.deferredCount.reserve(1);
+        cache.deferredCount.zero(tracer->stream);
         rtd::launchGatherCollect(tracer->view, camera, stride, pixels, cache.counts.ptr, stats.ptr, cache.slots.ptr,
-                                 tracer->stream);
+                                 cache.deferred.ptr, cache.deferredCount.ptr, tracer->stream);
     }
     else
     {

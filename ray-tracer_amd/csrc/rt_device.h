@@ -1820,7 +1820,10 @@ RT_DEV double reflectedFootprintRadius(double tanPixelHalfAngle, double unfolded
 // One pixel of ProbeGather::collectGatherPoints, reference src/ProbeGather.cpp:286-457.
 // Calls emit(point) for every surviving sample, in the reference's order; returns the
 // number of survivors.  stats[0..2] += camera rays, delta extensions, misses.
-template <class Emit>
+// DeferDelta (for pixels of one sample only): a pixel whose camera ray meets a delta surface is left
+// alone — nothing emitted, nothing counted, -1 returned — for a second launch that follows the ray on
+// (this instance then holds none of the code that does).
+template <bool DeferDelta = false, class Emit>
 RT_DEV int collectPixel(const SceneView& s, int32_t cameraIndex, int32_t px, int32_t py, unsigned long long* stats,
                         Emit&& emit)
 {
@@ -1878,6 +1881,11 @@ RT_DEV int collectPixel(const SceneView& s, int32_t cameraIndex, int32_t px, int
             emit(gp, survived);
             survived += 1;
             continue;
+        }
+        if (DeferDelta)
+        {
+            stats[0] -= 1;
+            return -1;
         }
         const bool stochasticDelta = s.materials[first.material].type == RT_MATERIAL_DIELECTRIC;
         const int extensionSamples = (stochasticDelta && !dofActive) ? 16 : 1;

@@ -192,8 +192,11 @@ void launchGatherWrite(const SceneView& scene, int32_t camera, int32_t stride, i
                        const uint64_t* offsets, GatherPoint* out, hipStream_t stream);
 // Probe pass of a camera whose pixels yield one record at most, in one launch of casts: every pixel's
 // record into slots[pixel], then (with the scan of the counts) the records moved into pixel-major order.
+// (deferred: `pixels` words, deferredCount: one, zero before the call — the pixels whose camera ray meets a mirror
+// are finished by a second launch)
 void launchGatherCollect(const SceneView& scene, int32_t camera, int32_t stride, int64_t pixels, uint32_t* counts,
-                         unsigned long long* stats, GatherPoint* slots, hipStream_t stream);
+                         unsigned long long* stats, GatherPoint* slots, uint32_t* deferred, unsigned long long* deferredCount,
+                         hipStream_t stream);
 void launchGatherCompact(const GatherPoint* slots, const uint32_t* counts, const uint64_t* offsets, int64_t pixels, GatherPoint* out,
                          hipStream_t stream);
 // The gather (ProbeGather::run) over the bounce store of the last pass.

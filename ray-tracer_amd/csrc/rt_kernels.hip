@@ -1237,16 +1237,71 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
 
 // Where a pixel has one sample at most (no shutter samples, no lens samples, no dielectric in the scene:
 // collectPixel's loops run once) a single pass of casts does: every pixel's record goes to the pixel's own
-// slot, and once the counts are scanned the records are moved to their places (no second cast).
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void gatherCollectKernel(const SceneView s, int32_t camera, int32_t stride, uint32_t* counts,
-                                    unsigned long long* stats, GatherPoint* slots)
+// slot, and the counts are scanned for the records' numbers (no second cast).  The pass is two launches: the
+// first casts every pixel's camera ray and finishes the pixels that see a diffuse surface or nothing — a lean
+// kernel, most pixels of most frames —, and lists the pixels that see a mirror; the second follows those
+// rays on with the whole of collectPixel (the mirror chain, the neighbouring pixel's chain for the
+// footprint: the kernel that does not fit its registers).
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void gatherPrimaryKernel(const SceneView s, int32_t camera, int32_t stride, uint32_t* counts,
+                                    unsigned long long* stats, GatherPoint* slots, uint32_t* deferred,
+                                    unsigned long long* deferredCount)
 {
     const Camera& cam = s.cameras[camera];
     const int32_t gw = (cam.width + stride - 1) / stride, gh = (cam.height + stride - 1) / stride;
     const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     unsigned long long local[3] = {0, 0, 0};
+    bool later = false;
     if (i < static_cast<int64_t>(gw) * gh)
     {
+        const int32_t px = static_cast<int32_t>(i % gw) * stride, py = static_cast<int32_t>(i / gw) * stride;
+        GatherPoint* dst = slots + i;
+        const int survived = collectPixel<true>(s, camera, px, py, local, [&](const GatherPoint& gp, int k) {
+            if (k == 0) *dst = gp;  // sampleWeight is 1 / 1 already
+        });
+        later = survived < 0;
+        counts[i] = later ? 0u : static_cast<uint32_t>(survived);
+    }
+    // the pixels left for the second launch, listed with one atomic a wave
+    const unsigned long long laterMask = __ballot(later);
+    if (laterMask != 0)
+    {
+        const int leader = __builtin_ctzll(laterMask);
+        unsigned long long base = 0;
+        if (static_cast<int>(threadIdx.x & 63) == leader)
+        {
+            base = atomicAdd(deferredCount, static_cast<unsigned long long>(__builtin_popcountll(laterMask)));
+        }
+        base = __shfl(base, leader, 64);
+        if (later) deferred[base + lanesBelow(laterMask)] = static_cast<uint32_t>(i);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+    {
+        const unsigned long long total = waveSum(local[k]);
+        if ((threadIdx.x & 63) == 0 && total != 0)
+        {
+            atomicAdd(stats + k, total);
+        }
+    }
+}
+
+// deferred == null: every pixel; else the pixels the list names (launched for the most there can be)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void gatherCollectKernel(const SceneView s, int32_t camera, int32_t stride, uint32_t* counts,
+                                    unsigned long long* stats, GatherPoint* slots, const uint32_t* deferred,
+                                    const unsigned long long* deferredCount)
+{
+    const Camera& cam = s.cameras[camera];
+    const int32_t gw = (cam.width + stride - 1) / stride, gh = (cam.height + stride - 1) / stride;
+    const int64_t q = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const int64_t listed = deferred ? static_cast<int64_t>(*deferredCount) : static_cast<int64_t>(gw) * gh;
+    if (static_cast<int64_t>(blockIdx.x) * blockDim.x >= listed)
+    {
+        return;  // the whole block lies beyond the list
+    }
+    unsigned long long local[3] = {0, 0, 0};
+    if (q < listed)
+    {
+        const int64_t i = deferred ? static_cast<int64_t>(deferred[q]) : q;
         const int32_t px = static_cast<int32_t>(i % gw) * stride, py = static_cast<int32_t>(i / gw) * stride;
         GatherPoint* dst = slots + i;
         counts[i] = static_cast<uint32_t>(collectPixel(s, camera, px, py, local, [&](const GatherPoint& gp, int k) {
@@ -2796,11 +2851,15 @@ void launchGatherWrite(const SceneView& scene, int32_t camera, int32_t stride, i
 }
 
 void launchGatherCollect(const SceneView& scene, int32_t camera, int32_t stride, int64_t pixels, uint32_t* counts,
-                         unsigned long long* stats, GatherPoint* slots, hipStream_t stream)
+                         unsigned long long* stats, GatherPoint* slots, uint32_t* deferred, unsigned long long* deferredCount,
+                         hipStream_t stream)
 {
     if (pixels <= 0) return;
-    hipLaunchKernelGGL(gatherCollectKernel, dim3(static_cast<uint32_t>((pixels + 63) / 64)), dim3(64), stackBytes(scene, 64), stream,
-                       scene, camera, stride, counts, stats, slots);
+    const dim3 grid(static_cast<uint32_t>((pixels + 63) / 64)), block(64);
+    hipLaunchKernelGGL(gatherPrimaryKernel, grid, block, stackBytes(scene, 64), stream, scene, camera, stride, counts, stats, slots,
+                       deferred, deferredCount);
+    hipLaunchKernelGGL(gatherCollectKernel, grid, block, stackBytes(scene, 64), stream, scene, camera, stride, counts, stats, slots,
+                       deferred, deferredCount);
 }
 
 void launchGatherCompact(const GatherPoint* slots, const uint32_t* counts, const uint64_t* offsets, int64_t pixels, GatherPoint* out,
