@@ -1412,9 +1412,11 @@ bool buildProbesOnDevice(rt_tracer* tracer, const double* probes, bool probesOnD
     space.listKeys[1].reserve(total);
     space.listEntries[0].reserve(total);
     space.listEntries[1].reserve(total);
-    rtd::launchBrickLists(space.groupKey.ptr, groups, space.listKeys[0].ptr, space.listEntries[0].ptr, stream);
     size_t mergeBytes = 0;
-    for (uint64_t width = groups; width < total; width *= 2)
+    check(rtd::mergeBrickLists(nullptr, &mergeBytes, space.groupKey.ptr, groups, 0, 1, space.listKeys[1].ptr, space.listEntries[1].ptr,
+                               stream),
+          "merge size query");
+    for (uint64_t width = 2 * groups; width < total; width *= 2)
     {
         size_t need = 0;
         check(rtd::mergeKeyPairs(nullptr, &need, space.listKeys[0].ptr, space.listEntries[0].ptr, width, space.listKeys[0].ptr,
@@ -1423,8 +1425,17 @@ bool buildProbesOnDevice(rt_tracer* tracer, const double* probes, bool probesOnD
         mergeBytes = std::max(mergeBytes, need);
     }
     space.mergeScratch.reserve(std::max<size_t>(mergeBytes, 1));
-    int from = 0;
-    for (uint64_t width = groups; width < total; width *= 2, from ^= 1)
+    // lists 0 + 1, 2 + 3, 4 + 5, 6 + 7 (straight from the groups), then the merges pair by pair
+    int from = 1;
+    for (int pairOfLists = 0; pairOfLists < 4; ++pairOfLists)
+    {
+        size_t need = mergeBytes;
+        check(rtd::mergeBrickLists(space.mergeScratch.ptr, &need, space.groupKey.ptr, groups, 2 * pairOfLists, 2 * pairOfLists + 1,
+                                   space.listKeys[from].ptr + 2 * groups * pairOfLists,
+                                   space.listEntries[from].ptr + 2 * groups * pairOfLists, stream),
+              "brick list merge");
+    }
+    for (uint64_t width = 2 * groups; width < total; width *= 2, from ^= 1)
     {
         for (uint64_t at = 0; at < total; at += 2 * width)
         {

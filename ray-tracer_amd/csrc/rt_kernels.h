@@ -317,12 +317,14 @@ void launchRunHeads(const unsigned long long* sortedKeys, uint64_t n, int shift,
 void launchDenseCells(const unsigned long long* sortedKeys, const uint32_t* sortedOrder, const uint64_t* ordinal,
                       const double* points, uint64_t n, DenseCell* cells, double* groupedPoints, hipStream_t stream);
 // The bricks (see ProbeView) are gathered from the groups of 2 x 2 x 2 cells: a record per group (fewer than
-// 2^29 of them), eight sorted lists of (brick, group) — list s in [s * groups, (s + 1) * groups) — that
-// the caller merges with mergeKeyPairs, and a table entry per run of equal bricks in the merged list.
+// 2^29 of them); eight sorted lists of (brick, group) — list s: every group's key less the packed offset s,
+// beside the group's number with s above it — that the caller merges pair by pair: the lists themselves
+// with mergeBrickLists (they are never written out), their merges with mergeKeyPairs; and a table entry per
+// run of equal bricks in the merged list.
 void launchCellGroups(const unsigned long long* sortedKeys, const uint64_t* cellOrdinal, const uint64_t* groupOrdinal, uint64_t n,
                       unsigned long long* groupKey, uint32_t* groupOwn, uint32_t* groupFirst, hipStream_t stream);
-void launchBrickLists(const unsigned long long* groupKey, uint64_t groups, unsigned long long* listKeys, uint32_t* listEntries,
-                      hipStream_t stream);
+hipError_t mergeBrickLists(void* scratch, size_t* scratchBytes, const unsigned long long* groupKey, uint64_t groups, int listA,
+                           int listB, unsigned long long* keysOut, uint32_t* entriesOut, hipStream_t stream);
 hipError_t mergeKeyPairs(void* scratch, size_t* scratchBytes, const unsigned long long* keysA, const uint32_t* valuesA, uint64_t nA,
                          const unsigned long long* keysB, const uint32_t* valuesB, uint64_t nB, unsigned long long* keysOut,
                          uint32_t* valuesOut, hipStream_t stream);

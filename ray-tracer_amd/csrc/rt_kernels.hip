@@ -2600,17 +2600,6 @@ __global__ void cellGroupsKernel(const unsigned long long* keys, const uint64_t*
     groupFirst[g] = static_cast<uint32_t>(cellOrdinal[i]);
 }
 
-// list s (entries [s * groups, (s + 1) * groups)): the brick each group lies in at offset s, and (s, group)
-__global__ void brickListsKernel(const unsigned long long* groupKey, uint64_t groups, unsigned long long* listKeys,
-                                 uint32_t* listEntries)
-{
-    const uint64_t t = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (t >= 8 * groups) return;
-    const uint64_t s = t / groups, g = t - s * groups;
-    listKeys[t] = groupKey[g] - ((s & 1) << 42) - (((s >> 1) & 1) << 21) - (s >> 2);
-    listEntries[t] = static_cast<uint32_t>(g) | (static_cast<uint32_t>(s) << kGroupIndexBits);
-}
-
 // the merged lists: the first entry of every brick gathers the brick and enters it into the table
 __global__ void bricksKernel(const unsigned long long* keys, const uint32_t* entries, uint64_t total, const uint32_t* groupOwn,
                              const uint32_t* groupFirst, ProbeBrick* bricks, uint64_t brickMask)
@@ -2621,18 +2610,38 @@ __global__ void bricksKernel(const unsigned long long* keys, const uint32_t* ent
     if (t != 0 && keys[t - 1] == key) return;
     unsigned long long vacant = ~0ull;
     uint32_t base0 = ~0u, base1 = ~0u, base2 = ~0u, base3 = ~0u;
-    for (uint64_t u = t; u < total && keys[u] == key; ++u)
+    // a brick has eight entries at most (one per group that lies in it): all of them are fetched before
+    // any is looked at, and the groups they name likewise — two round trips, not one per entry
+    constexpr int kMost = 8;
+    uint32_t entry[kMost], own[kMost], first[kMost];
+    bool mine[kMost];
+    bool sofar = true;
+#pragma unroll
+    for (int k = 0; k < kMost; ++k)
     {
-        const uint32_t entry = entries[u];
-        const uint32_t g = entry & ((1u << kGroupIndexBits) - 1u);
-        const int sx = (entry >> kGroupIndexBits) & 1, sy = (entry >> (kGroupIndexBits + 1)) & 1, sz = entry >> (kGroupIndexBits + 2);
-        vacant &= ~(static_cast<unsigned long long>(groupOwn[g]) << (2 * sx + 8 * sy + 32 * sz));
-        const uint32_t first = groupFirst[g];
+        const uint64_t u = t + k < total ? t + k : total - 1;
+        mine[k] = sofar && t + k < total && keys[u] == key;
+        sofar = mine[k];
+        entry[k] = entries[u];
+    }
+#pragma unroll
+    for (int k = 0; k < kMost; ++k)
+    {
+        const uint32_t g = entry[k] & ((1u << kGroupIndexBits) - 1u);
+        own[k] = groupOwn[g];
+        first[k] = groupFirst[g];
+    }
+#pragma unroll
+    for (int k = 0; k < kMost; ++k)
+    {
+        if (!mine[k]) continue;
+        const int sx = (entry[k] >> kGroupIndexBits) & 1, sy = (entry[k] >> (kGroupIndexBits + 1)) & 1, sz = entry[k] >> (kGroupIndexBits + 2);
+        vacant &= ~(static_cast<unsigned long long>(own[k]) << (2 * sx + 8 * sy + 32 * sz));
         const int column = sx + 2 * sy;
-        base0 = column == 0 ? min(base0, first) : base0;
-        base1 = column == 1 ? min(base1, first) : base1;
-        base2 = column == 2 ? min(base2, first) : base2;
-        base3 = column == 3 ? min(base3, first) : base3;
+        base0 = column == 0 ? min(base0, first[k]) : base0;
+        base1 = column == 1 ? min(base1, first[k]) : base1;
+        base2 = column == 2 ? min(base2, first[k]) : base2;
+        base3 = column == 3 ? min(base3, first[k]) : base3;
     }
     const int64_t mx = static_cast<int64_t>(key >> 42) - kPackLimit;
     const int64_t my = static_cast<int64_t>((key >> 21) & ((1ull << 21) - 1)) - kPackLimit;
@@ -3102,12 +3111,31 @@ void launchCellGroups(const unsigned long long* sortedKeys, const uint64_t* cell
                        groupOrdinal, n, groupKey, groupOwn, groupFirst);
 }
 
-void launchBrickLists(const unsigned long long* groupKey, uint64_t groups, unsigned long long* listKeys, uint32_t* listEntries,
-                      hipStream_t stream)
+namespace
 {
-    if (groups == 0) return;
-    hipLaunchKernelGGL(brickListsKernel, dim3(gridFor(static_cast<int64_t>(8 * groups))), dim3(256), 0, stream, groupKey, groups,
-                       listKeys, listEntries);
+struct LessBy
+{
+    unsigned long long by;
+    __host__ __device__ unsigned long long operator()(unsigned long long key) const { return key - by; }
+};
+}  // namespace
+
+// the first merges read the lists straight from the groups' records: list s is "the group's key less the
+// packed offset s" beside "the group's number with s above it"
+hipError_t mergeBrickLists(void* scratch, size_t* scratchBytes, const unsigned long long* groupKey, uint64_t groups, int listA,
+                           int listB, unsigned long long* keysOut, uint32_t* entriesOut, hipStream_t stream)
+{
+    auto offsetOf = [](int s) {
+        return (static_cast<unsigned long long>(s & 1) << 42) + (static_cast<unsigned long long>((s >> 1) & 1) << 21) +
+               static_cast<unsigned long long>(s >> 2);
+    };
+    typedef hipcub::TransformInputIterator<unsigned long long, LessBy, const unsigned long long*> Keys;
+    typedef hipcub::CountingInputIterator<uint32_t> Entries;
+    return hipcub::DeviceMerge::MergePairs(scratch, *scratchBytes, Keys(groupKey, LessBy{offsetOf(listA)}),
+                                           Entries(static_cast<uint32_t>(listA) << kGroupIndexBits), static_cast<int>(groups),
+                                           Keys(groupKey, LessBy{offsetOf(listB)}),
+                                           Entries(static_cast<uint32_t>(listB) << kGroupIndexBits), static_cast<int>(groups),
+                                           keysOut, entriesOut, ::rocprim::less<unsigned long long>(), stream);
 }
 
 hipError_t mergeKeyPairs(void* scratch, size_t* scratchBytes, const unsigned long long* keysA, const uint32_t* valuesA, uint64_t nA,
