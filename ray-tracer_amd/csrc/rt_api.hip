@@ -1240,7 +1240,9 @@ rt_tracer::GatherCache& ensureGatherPoints(rt_tracer* tracer, int32_t camera)
     // one record a pixel at most (collectPixel's sample loops run once): one pass of casts does
     const bool lensSamples = cam.projection == RT_PROJECTION_REALLENS && cam.apertureRadius > 0.0;
     const bool shutterSamples = tracer->view.shutterSpan > 0.0f && tracer->view.cameraTimeSamples > 1;
-    const bool onePass = !lensSamples && !shutterSamples && !tracer->hasDielectric;
+    // (RT_AMD_PROBE_PASS=two takes such a camera through the count-then-write form as well: for tests)
+    const char* form = std::getenv("RT_AMD_PROBE_PASS");
+    const bool onePass = !lensSamples && !shutterSamples && !tracer->hasDielectric && !(form != nullptr && std::string(form) == "two");
     if (onePass)
     {
         cache.slots.reserve(static_cast<size_t>(std::max<int64_t>(pixels, 1)));

@@ -561,6 +561,48 @@ def test_probe_pass_equals_reference_where_rng_free(rt, golden, manifest, scene_
     assert_bits_equal(direct_got, direct_want, "RNG-free gather points vs reference")
 
 
+def test_probe_pass_in_one_pass_of_casts_equals_count_then_write(rt, scene_opener, monkeypatch):
+    """A camera whose pixels yield one record at most (no lens or shutter samples, no dielectric in the scene)
+    is collected in one pass of casts — a lean launch for every pixel's camera ray, a second one for the pixels
+    that see a mirror, records left at their pixels until somebody asks for them — and otherwise by counting
+    and then writing: the same records to the bit, the same counts, and the same again after
+    rt_forget_gather_points; the set-up's timings are those of the run that was made."""
+    entry = {"scene": "scenes/MirrorBombardment-200M.json", "photons_per_light": 20000, "image": 160, "seed": 11}
+    scene, tracer, orc = _open(rt, scene_opener, entry)
+    setup = O.frame_setup(orc, O.RNG_COUNTER, O.MATH_PORTABLE)
+    keep = setup["keep_radius"]
+    points, stats = tracer.collect_gather_points(0)
+    assert len(points) > 1000 and stats["delta_extensions"] > 0, "some pixels see the mirror"
+    probes, capacity = tracer.set_probes_from_cameras(keep, keep, 256, int(scene.settings.bounce_store_capacity))
+    assert probes == len(points)
+    timings = tracer.setup_timings()
+    assert timings["probe_pass"] > 0 and timings["index_build"] > 0 and timings["filter_build"] > 0
+    tracer.reset()
+    tracer.trace(sink_mode=1)
+    tracer.gather(0, setup["gather_cell"], setup["min_gather_radius"])
+    counters, store = tracer.counters(), _sorted_records(tracer.store())
+    buffer = tracer.camera_buffer(0).copy()
+
+    tracer.forget_gather_points()
+    again, stats_again = tracer.collect_gather_points(0)
+    assert_bits_equal(again, points, "the pass run again")
+    assert stats_again == stats
+
+    monkeypatch.setenv("RT_AMD_PROBE_PASS", "two")
+    other = rt.Tracer(scene)
+    two, stats_two = other.collect_gather_points(0)
+    assert_bits_equal(two, points, "count then write")
+    assert stats_two == stats
+    assert other.set_probes_from_cameras(keep, keep, 256, int(scene.settings.bounce_store_capacity)) == (probes, capacity)
+    other.reset()
+    other.trace(sink_mode=1)
+    other.gather(0, setup["gather_cell"], setup["min_gather_radius"])
+    for k in ("photons", "casts", "bounces", "deposits", "kept", "culled", "store_size"):
+        assert other.counters()[k] == counters[k], k
+    assert_bits_equal(_sorted_records(other.store()), store, "store records")
+    assert_bits_equal(other.camera_buffer(0), buffer, "gathered frame")
+
+
 @pytest.mark.parametrize("name", ["mixed", "multicam", "animated"])
 def test_probes_from_cameras_equal_probes_through_the_host(rt, scene_opener, name):
     """rt_set_probes_from_cameras builds the keep-test index from the probe-pass records on the
