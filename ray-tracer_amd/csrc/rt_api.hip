@@ -2386,13 +2386,26 @@ int32_t rt_trace(rt_tracer* tracer, const rt_trace_params* params)
                       "emission order, first digit");
                 // (the list of keys by id has been read: it takes the sorted keys)
                 const int skipBits = rtd::kRefineBits + rtd::kDigitBits;
-                check(rtd::sortEmissionPairs(nullptr, &bytes, tracer->sortKeysOut.ptr, tracer->sortKeysIn.ptr, tracer->sortIds.ptr,
-                                             tracer->sortOrder.ptr, n, lights, skipBits, tracer->stream),
-                      "sort size query");
-                if (tracer->sortScratch.count < bytes) tracer->sortScratch.allocate(bytes);
-                check(rtd::sortEmissionPairs(tracer->sortScratch.ptr, &bytes, tracer->sortKeysOut.ptr, tracer->sortKeysIn.ptr,
-                                             tracer->sortIds.ptr, tracer->sortOrder.ptr, n, lights, skipBits, tracer->stream),
-                      "emission sort");
+                const char* second = std::getenv("RT_AMD_EMISSION_SECOND");  // "library": the radix pass for one light too
+                if (lights == 1 && !(second != nullptr && std::strcmp(second, "library") == 0))
+                {
+                    // one light: the keys end eight bits above the first digit, and a pass of our own places them
+                    // (the matrix of counts and the scan's work space are those of the first digit)
+                    check(rtd::topDigitOrder(n, tracer->sortScratch.ptr, &bytes, tracer->sortKeysOut.ptr, tracer->sortIds.ptr,
+                                             tracer->orderCounts.ptr, tracer->orderOffsets.ptr, tracer->sortKeysIn.ptr,
+                                             tracer->sortOrder.ptr, tracer->stream),
+                          "emission order, second digit");
+                }
+                else
+                {
+                    check(rtd::sortEmissionPairs(nullptr, &bytes, tracer->sortKeysOut.ptr, tracer->sortKeysIn.ptr, tracer->sortIds.ptr,
+                                                 tracer->sortOrder.ptr, n, lights, skipBits, tracer->stream),
+                          "sort size query");
+                    if (tracer->sortScratch.count < bytes) tracer->sortScratch.allocate(bytes);
+                    check(rtd::sortEmissionPairs(tracer->sortScratch.ptr, &bytes, tracer->sortKeysOut.ptr, tracer->sortKeysIn.ptr,
+                                                 tracer->sortIds.ptr, tracer->sortOrder.ptr, n, lights, skipBits, tracer->stream),
+                          "emission sort");
+                }
                 rtd::launchRefineOrder(tracer->sortKeysIn.ptr, tracer->sortOrder.ptr, n, tracer->sortIds.ptr, tracer->stream);
                 tracer->orderList = tracer->sortIds.ptr;
                 check(hipGetLastError(), "emission sort");

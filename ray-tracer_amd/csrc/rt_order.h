@@ -81,9 +81,9 @@ RT_DEV uint32_t emissionCell(const TraceArgs& a, int lightId, unsigned long long
 //      a tile of consecutive ids, works out their keys (kept) and counts them by that digit in LDS, the
 //      counts go to a [digit][tile] matrix, one exclusive sum over the matrix is where every (digit, tile)
 //      starts, and the tiles then place their (key, id) pairs, gathered by digit in LDS so that whole runs
-//      are written.  No order has to be kept among equal digits (it is the first digit sorted), which is
-//      what makes the ranks a matter of LDS atomics;
-//   2. a stable radix pass (the library's) over the bits above;
+//      are written;
+//   2. a stable pass over the bits above: one like step 1 whose ranks are counted in arrival order (keys of
+//      one light: eight bits), else the library's radix pass;
 //   3. every run of kRefineRun consecutive positions of that list is put in the order of the whole key
 //      inside LDS.  The order is a schedule (any permutation of the ids is a correct one): a wave works
 //      through a run of at most kRefineRun positions, and inside such a run the ids are then exactly as
@@ -99,6 +99,10 @@ inline uint64_t digitMatrixEntries(uint64_t n) { return digitTiles(n) << kDigitB
 // runs and *scratchBytes receives the exclusive sum's work space.
 hipError_t digitOrder(const TraceArgs& args, void* scratch, size_t* scratchBytes, uint32_t* keys, uint32_t* counts,
                       uint32_t* offsets, uint32_t* keysOut, uint32_t* idsOut, hipStream_t stream);
+// Step 2 for keys of one light (24 bits): keys / ids, the pairs by the digit of step 1, go to keysOut / idsOut
+// by the eight bits above it, pairs of equal bits in the order they arrive in.  counts / offsets as in step 1.
+hipError_t topDigitOrder(uint64_t n, void* scratch, size_t* scratchBytes, const uint32_t* keys, const uint32_t* ids, uint32_t* counts,
+                         uint32_t* offsets, uint32_t* keysOut, uint32_t* idsOut, hipStream_t stream);
 // Step 3.  keys / ids: the pairs in ascending order of (key >> kRefineBits); order: n words (the result)
 void launchRefineOrder(const uint32_t* keys, const uint32_t* ids, uint64_t n, uint32_t* order, hipStream_t stream);
 

@@ -54,21 +54,109 @@ __global__ __launch_bounds__(kDigitThreads) void digitCountKernel(const TraceArg
     if (threadIdx.x < kDigits) counts[threadIdx.x * tiles + tile] = histogram[threadIdx.x];
 }
 
-__global__ __launch_bounds__(kDigitThreads) void digitScatterKernel(uint64_t n, uint64_t tiles, uint64_t tilesPerXcd,
-                                                                    const uint32_t* keys, const uint32_t* counts,
-                                                                    const uint32_t* offsets, uint32_t* keysOut, uint32_t* idsOut)
+// ---- placing the pairs of a tile (steps 1 and 2) ----
+// Given the exclusive sum of the [digit][tile] counts, a tile's pairs are gathered by digit in LDS and written
+// out run by run.  A pair's place among its tile's pairs of the same digit is COUNTED, in arrival order: a wave
+// takes 64 consecutive pairs at a time, the lanes with the same digit find each other with one ballot per bit
+// of the digit, a pair's rank is the digit's count so far in its wave (kept in LDS, advanced by the first of
+// the lanes that share it) plus the lanes before it among those; the waves' counts are then summed in wave
+// order.  Step 2 needs that (pairs of equal digit must keep the order of step 1); step 1 does not, but ranks
+// claimed with LDS atomics — 8192 pairs on 256 counters — cost it 0.9 ms where these cost 0.73, and the
+// library's one-sweep pass, which this replaces in step 2 for keys of one light, moves the pairs at 2.3 TB/s
+// where this moves them at 4.
+constexpr int kTopWaves = kDigitThreads / 64;
+constexpr int kTopSteps = kDigitTile / kDigitThreads;  // times a wave takes 64 pairs
+static_assert(kDigitTile == kTopWaves * kTopSteps * 64, "a wave's pairs are consecutive");
+
+RT_DEV uint32_t topDigitOf(uint32_t key) { return (key >> (kRefineBits + kDigitBits)) & (kDigits - 1); }
+
+__global__ __launch_bounds__(kDigitThreads) void topCountKernel(uint64_t n, uint64_t tiles, uint64_t tilesPerXcd,
+                                                                const uint32_t* keys, uint32_t* counts)
 {
-    __shared__ uint32_t cursor[kDigits];     // next free place of every digit in the gathered tile
-    __shared__ uint32_t localStart[kDigits]; // where the digit's run starts in the gathered tile ...
-    __shared__ uint32_t globalStart[kDigits];// ... and in the list
-    __shared__ uint32_t waveTotals[kDigitThreads / 64];
+    __shared__ uint32_t histogram[kDigits];
+    const uint64_t tile = digitTileOfBlock(tilesPerXcd);
+    if (tile >= tiles) return;
+    if (threadIdx.x < kDigits) histogram[threadIdx.x] = 0;
+    __syncthreads();
+    const unsigned long long begin = tile * kDigitTile;
+#pragma unroll 4
+    for (int k = 0; k < kDigitItems; ++k)
+    {
+        const unsigned long long i = begin + static_cast<unsigned long long>(k) * kDigitThreads + threadIdx.x;
+        if (i < n) atomicAdd(&histogram[topDigitOf(keys[i])], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < kDigits) counts[threadIdx.x * tiles + tile] = histogram[threadIdx.x];
+}
+
+// First: the digit of step 1, and a pair's id is its place in the list (ids is null)
+template <bool First>
+__global__ __launch_bounds__(kDigitThreads) void stableScatterKernel(uint64_t n, uint64_t tiles, uint64_t tilesPerXcd,
+                                                                     const uint32_t* keys, const uint32_t* ids,
+                                                                     const uint32_t* offsets, uint32_t* keysOut, uint32_t* idsOut)
+{
+    auto digitHere = [](uint32_t key) { return First ? digitOf(key) : topDigitOf(key); };
+    __shared__ uint32_t waveCount[kTopWaves][kDigits];  // pairs of a digit in a wave's part of the tile, then those of the waves before it
+    __shared__ uint32_t localStart[kDigits];            // where the digit's run starts in the gathered tile ...
+    __shared__ uint32_t globalStart[kDigits];           // ... and in the list
+    __shared__ uint32_t waveTotals[kTopWaves];
     __shared__ uint32_t gatheredKey[kDigitTile];
-    __shared__ uint16_t gatheredFrom[kDigitTile];  // the pair's place in the tile: its id is the tile's first + that
+    __shared__ uint32_t gatheredId[kDigitTile];
     const uint64_t tile = digitTileOfBlock(tilesPerXcd);
     if (tile >= tiles) return;
     const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    // exclusive sum of the tile's digit counts (a thread per digit)
-    const uint32_t mine = t < kDigits ? counts[t * tiles + tile] : 0u;
+    for (uint32_t k = t; k < kTopWaves * kDigits; k += kDigitThreads) (&waveCount[0][0])[k] = 0;
+    __syncthreads();
+    const unsigned long long begin = tile * kDigitTile;
+    const uint32_t count = n - begin < kDigitTile ? static_cast<uint32_t>(n - begin) : kDigitTile;
+    uint32_t key[kTopSteps], id[kTopSteps], rank[kTopSteps];
+#pragma unroll
+    for (int step = 0; step < kTopSteps; ++step)
+    {
+        const uint32_t i = (wave * kTopSteps + step) * 64 + lane;
+        const bool there = i < count;
+        key[step] = there ? keys[begin + i] : 0u;
+        id[step] = there ? (First ? static_cast<uint32_t>(begin) + i : ids[begin + i]) : 0u;
+    }
+#pragma unroll
+    for (int step = 0; step < kTopSteps; ++step)
+    {
+        const uint32_t i = (wave * kTopSteps + step) * 64 + lane;
+        const bool there = i < count;
+        const uint32_t digit = digitHere(key[step]);
+        unsigned long long peers = __ballot(there);
+#pragma unroll
+        for (int bit = 0; bit < kDigitBits; ++bit)
+        {
+            const bool set = ((digit >> bit) & 1u) != 0;
+            const unsigned long long with = __ballot(set);
+            peers &= set ? with : ~with;
+        }
+        // (a lane that holds no pair is among the peers of nobody: `there` is in every lane's mask)
+        const int first = there ? __builtin_ctzll(peers) : static_cast<int>(lane);
+        uint32_t before = 0;
+        if (there && static_cast<int>(lane) == first)
+        {
+            before = waveCount[wave][digit];
+            waveCount[wave][digit] = before + static_cast<uint32_t>(__builtin_popcountll(peers));
+        }
+        before = __shfl(before, first, 64);
+        rank[step] = before + static_cast<uint32_t>(__builtin_popcountll(peers & ((1ull << lane) - 1ull)));
+    }
+    __syncthreads();
+    // a thread per digit: the waves' counts become the counts of the waves before them, the digit's total
+    // goes into the exclusive sum over the digits
+    uint32_t mine = 0;
+    if (t < kDigits)
+    {
+#pragma unroll
+        for (int w = 0; w < kTopWaves; ++w)
+        {
+            const uint32_t c = waveCount[w][t];
+            waveCount[w][t] = mine;
+            mine += c;
+        }
+    }
     uint32_t inclusive = mine;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1)
@@ -80,26 +168,22 @@ __global__ __launch_bounds__(kDigitThreads) void digitScatterKernel(uint64_t n, 
     __syncthreads();
     if (t < kDigits)
     {
-        uint32_t before = 0;
-        for (uint32_t w = 0; w < wave; ++w) before += waveTotals[w];
-        const uint32_t exclusive = before + inclusive - mine;
-        cursor[t] = exclusive;
-        localStart[t] = exclusive;
+        uint32_t beforeWaves = 0;
+        for (uint32_t w = 0; w < wave; ++w) beforeWaves += waveTotals[w];
+        localStart[t] = beforeWaves + inclusive - mine;
         globalStart[t] = offsets[t * tiles + tile];
     }
     __syncthreads();
-    const unsigned long long begin = tile * kDigitTile;
-    const uint32_t count = n - begin < kDigitTile ? static_cast<uint32_t>(n - begin) : kDigitTile;
-#pragma unroll 4
-    for (int k = 0; k < kDigitItems; ++k)
+#pragma unroll
+    for (int step = 0; step < kTopSteps; ++step)
     {
-        const uint32_t i = static_cast<uint32_t>(k) * kDigitThreads + t;
+        const uint32_t i = (wave * kTopSteps + step) * 64 + lane;
         if (i < count)
         {
-            const uint32_t key = keys[begin + i];
-            const uint32_t at = atomicAdd(&cursor[digitOf(key)], 1u);
-            gatheredKey[at] = key;
-            gatheredFrom[at] = static_cast<uint16_t>(i);
+            const uint32_t digit = digitHere(key[step]);
+            const uint32_t at = localStart[digit] + waveCount[wave][digit] + rank[step];
+            gatheredKey[at] = key[step];
+            gatheredId[at] = id[step];
         }
     }
     __syncthreads();
@@ -109,11 +193,11 @@ __global__ __launch_bounds__(kDigitThreads) void digitScatterKernel(uint64_t n, 
         const uint32_t i = static_cast<uint32_t>(k) * kDigitThreads + t;
         if (i < count)
         {
-            const uint32_t key = gatheredKey[i];
-            const uint32_t digit = digitOf(key);
+            const uint32_t k32 = gatheredKey[i];
+            const uint32_t digit = digitHere(k32);
             const uint32_t at = globalStart[digit] + (i - localStart[digit]);
-            keysOut[at] = key;
-            idsOut[at] = static_cast<uint32_t>(begin) + gatheredFrom[i];
+            keysOut[at] = k32;
+            idsOut[at] = gatheredId[i];
         }
     }
 }
@@ -259,7 +343,26 @@ hipError_t digitOrder(const TraceArgs& args, void* scratch, size_t* scratchBytes
     const hipError_t scanned =
         hipcub::DeviceScan::ExclusiveSum(scratch, *scratchBytes, counts, offsets, static_cast<int>(entries), stream);
     if (scanned != hipSuccess) return scanned;
-    hipLaunchKernelGGL(digitScatterKernel, grid, block, 0, stream, n, tiles, tilesPerXcd, keys, counts, offsets, keysOut, idsOut);
+    hipLaunchKernelGGL(stableScatterKernel<true>, grid, block, 0, stream, n, tiles, tilesPerXcd, keys, nullptr, offsets, keysOut, idsOut);
+    return hipGetLastError();
+}
+
+hipError_t topDigitOrder(uint64_t n, void* scratch, size_t* scratchBytes, const uint32_t* keys, const uint32_t* ids, uint32_t* counts,
+                         uint32_t* offsets, uint32_t* keysOut, uint32_t* idsOut, hipStream_t stream)
+{
+    const uint64_t tiles = digitTiles(n), entries = digitMatrixEntries(n);
+    if (scratch == nullptr)
+    {
+        return hipcub::DeviceScan::ExclusiveSum(nullptr, *scratchBytes, counts, offsets, static_cast<int>(entries), stream);
+    }
+    if (n == 0) return hipSuccess;
+    const uint64_t tilesPerXcd = (tiles + kOrderXcds - 1) / kOrderXcds;
+    const dim3 grid(static_cast<unsigned int>(tilesPerXcd * kOrderXcds)), block(kDigitThreads);
+    hipLaunchKernelGGL(topCountKernel, grid, block, 0, stream, n, tiles, tilesPerXcd, keys, counts);
+    const hipError_t scanned =
+        hipcub::DeviceScan::ExclusiveSum(scratch, *scratchBytes, counts, offsets, static_cast<int>(entries), stream);
+    if (scanned != hipSuccess) return scanned;
+    hipLaunchKernelGGL(stableScatterKernel<false>, grid, block, 0, stream, n, tiles, tilesPerXcd, keys, ids, offsets, keysOut, idsOut);
     return hipGetLastError();
 }
 
