@@ -723,6 +723,13 @@ def test_keep_test_equals_the_scan_over_all_probes(rt, scene_opener, cell_over_k
         want[start:start + 512] = (d2 <= keep * keep).any(1)
     assert want[:3000].all() and 0.2 < want.mean() < 0.9
     assert np.array_equal(got.astype(bool), want), np.nonzero(got.astype(bool) != want)[0][:10]
+    # the smallest grids: one probe, and a handful in one cell
+    for few in (probes[:1], crowded2):
+        tracer.set_probes(few, cell, keep, 64)
+        near = few[0] + directions[:200] * rng.uniform(0, 2.0, (200, 1)) * keep
+        d = few[None, :, :] - near[:, None, :]
+        d2 = d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1] + d[..., 2] * d[..., 2]
+        assert np.array_equal(tracer.probe_keep_test(near).astype(bool), (d2 <= keep * keep).any(1))
 
 
 GATHER_SCENES = {
