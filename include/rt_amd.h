@@ -204,9 +204,9 @@ void rt_debug_device_allocations(uint64_t* allocations, uint64_t* releases);
 int32_t rt_debug_device_memory(int32_t device, uint64_t* free_bytes, uint64_t* total_bytes);
 
 /* Device time of the last rt_trace, from HIP events recorded on the tracer's stream around
- * its two stages: the emission-order sort of the photon ids (a bucket sort by emission cell for a
- * pass of one light and 4 Mi ids or more, else keys + radix sort; 0 when the pass has 2^31 ids or
- * more and is traced unsorted) and the trace kernel.  The reference reports one wall time for the whole pass
+ * its two stages: the emission-order sort of the photon ids (two digits of the emission cell placed
+ * tile by tile and the low bits run by run for a pass of 1 Mi to 256 Mi ids, else keys + radix sort; 0
+ * when the pass has 2^31 ids or more and is traced unsorted) and the trace kernel.  The reference reports one wall time for the whole pass
  * (RenderResult::photonPassSeconds, include/Renderer.h:51-103); the split is what a
  * per-kernel roofline needs.  Waits for the pass to finish. */
 int32_t rt_read_timings(rt_tracer* tracer, float* sort_ms, float* trace_ms);

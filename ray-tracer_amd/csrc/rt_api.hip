@@ -182,7 +182,7 @@ unsigned char* staticScratchOf(int device)
 constexpr int kQueueLevels = 12;
 constexpr uint64_t kQueueCapacity = 48ull << 20;  // photons parked per level at most (4.5 GB per queue)
 constexpr uint64_t kQueueMinimumWork = 4ull << 20;  // smaller passes are traced in one launch
-constexpr uint64_t kRefineOrderMinimum = 4ull << 20;  // smaller passes are radix-sorted over all the bits of their keys
+constexpr uint64_t kRefineOrderMinimum = 1ull << 20;  // smaller passes are radix-sorted over all the bits of their keys (fewer launches)
 
 struct rt_tracer
 {
