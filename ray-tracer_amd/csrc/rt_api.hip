@@ -182,6 +182,7 @@ unsigned char* staticScratchOf(int device)
 constexpr int kQueueLevels = 12;
 constexpr uint64_t kQueueCapacity = 48ull << 20;  // photons parked per level at most (4.5 GB per queue)
 constexpr uint64_t kQueueMinimumWork = 4ull << 20;  // smaller passes are traced in one launch
+constexpr uint64_t kOwnLevelSortMinimum = 1ull << 20;  // parked photons from which the sort's passes are our own
 constexpr uint64_t kRefineOrderMinimum = 1ull << 20;  // smaller passes are radix-sorted over all the bits of their keys (fewer launches)
 
 struct rt_tracer
@@ -269,7 +270,7 @@ struct rt_tracer
     uint64_t orderedLength = 0;                   // ids in the emission order of the last rt_trace (0: traced unsorted)
     DeviceArray<rtd::PhotonState> photonQueue[2];
     // keys of the parked photons' rays, their sorted copy, the slot numbers in key order, 0..n-1
-    DeviceArray<uint32_t> queueKeys, queueKeysSorted, queueOrder, queueIota;
+    DeviceArray<uint32_t> queueKeys, queueKeysSorted, queueOrder, queueIota, queueSpare;
     float keyOrigin[3] = {0.0f, 0.0f, 0.0f};
     float keyScale = 1.0f;
 
@@ -2391,9 +2392,9 @@ int32_t rt_trace(rt_tracer* tracer, const rt_trace_params* params)
                 {
                     // one light: the keys end eight bits above the first digit, and a pass of our own places them
                     // (the matrix of counts and the scan's work space are those of the first digit)
-                    check(rtd::topDigitOrder(n, tracer->sortScratch.ptr, &bytes, tracer->sortKeysOut.ptr, tracer->sortIds.ptr,
-                                             tracer->orderCounts.ptr, tracer->orderOffsets.ptr, tracer->sortKeysIn.ptr,
-                                             tracer->sortOrder.ptr, tracer->stream),
+                    check(rtd::stableDigitPass(n, skipBits, tracer->sortScratch.ptr, &bytes, tracer->sortKeysOut.ptr, tracer->sortIds.ptr,
+                                               tracer->orderCounts.ptr, tracer->orderOffsets.ptr, tracer->sortKeysIn.ptr,
+                                               tracer->sortOrder.ptr, tracer->stream),
                           "emission order, second digit");
                 }
                 else
@@ -2472,6 +2473,7 @@ int32_t rt_trace(rt_tracer* tracer, const rt_trace_params* params)
             tracer->queueKeysSorted.allocate(capacity);
             tracer->queueOrder.allocate(capacity);
             tracer->queueIota.allocate(capacity);
+            tracer->queueSpare.allocate(capacity);
             rtd::launchIota(tracer->queueIota.ptr, capacity, tracer->stream);
         }
         if (levels > 0 && tracer->queueCounts.count == 0)
@@ -2551,7 +2553,39 @@ int32_t rt_trace(rt_tracer* tracer, const rt_trace_params* params)
                 break;
             }
             sortedLevel = levelSort && parked >= sortMinimum;
-            if (sortedLevel)
+            // (RT_AMD_LEVEL_SORTER=library: the library's radix sort whatever the size)
+            const char* levelSorter = std::getenv("RT_AMD_LEVEL_SORTER");
+            if (sortedLevel && parked >= kOwnLevelSortMinimum && !(levelSorter != nullptr && std::strcmp(levelSorter, "library") == 0))
+            {
+                // Stable passes of our own over the key's bits, eight at a time (rt_order.h): they move the pairs
+                // at twice the library's rate.  The pairs go back and forth between two sets of lists; the first
+                // pass takes the photons' places in the queue as its ids and is aimed so that the last one ends
+                // in queueOrder.
+                const uint64_t entries = rtd::digitMatrixEntries(parked);
+                if (tracer->orderCounts.count < entries)
+                {
+                    tracer->orderCounts.allocate(entries);
+                    tracer->orderOffsets.allocate(entries);
+                }
+                size_t bytes = 0;
+                check(rtd::stableDigitPass(parked, 0, nullptr, &bytes, nullptr, nullptr, tracer->orderCounts.ptr, tracer->orderOffsets.ptr,
+                                           nullptr, nullptr, tracer->stream),
+                      "scan size query");
+                if (tracer->sortScratch.count < bytes) tracer->sortScratch.allocate(bytes);
+                const int passes = (keyBits + 7) / 8;
+                uint32_t* keyLists[2] = {tracer->queueKeys.ptr, tracer->queueKeysSorted.ptr};
+                uint32_t* idLists[2] = {tracer->queueOrder.ptr, tracer->queueSpare.ptr};
+                int idsAt = passes % 2 == 1 ? 1 : 0;  // the list the NEXT pass reads its ids from (none for the first)
+                for (int pass = 0; pass < passes; ++pass)
+                {
+                    check(rtd::stableDigitPass(parked, 8 * pass, tracer->sortScratch.ptr, &bytes, keyLists[pass & 1],
+                                               pass == 0 ? nullptr : idLists[idsAt], tracer->orderCounts.ptr, tracer->orderOffsets.ptr,
+                                               keyLists[(pass & 1) ^ 1], idLists[idsAt ^ 1], tracer->stream),
+                          "parked photon sort");
+                    idsAt ^= 1;
+                }
+            }
+            else if (sortedLevel)
             {
                 size_t bytes = 0;
                 check(rtd::sortPairs32(nullptr, &bytes, tracer->queueKeys.ptr, tracer->queueKeysSorted.ptr, tracer->queueIota.ptr,

@@ -99,10 +99,12 @@ inline uint64_t digitMatrixEntries(uint64_t n) { return digitTiles(n) << kDigitB
 // runs and *scratchBytes receives the exclusive sum's work space.
 hipError_t digitOrder(const TraceArgs& args, void* scratch, size_t* scratchBytes, uint32_t* keys, uint32_t* counts,
                       uint32_t* offsets, uint32_t* keysOut, uint32_t* idsOut, hipStream_t stream);
-// Step 2 for keys of one light (24 bits): keys / ids, the pairs by the digit of step 1, go to keysOut / idsOut
-// by the eight bits above it, pairs of equal bits in the order they arrive in.  counts / offsets as in step 1.
-hipError_t topDigitOrder(uint64_t n, void* scratch, size_t* scratchBytes, const uint32_t* keys, const uint32_t* ids, uint32_t* counts,
-                         uint32_t* offsets, uint32_t* keysOut, uint32_t* idsOut, hipStream_t stream);
+// One stable pass of a sort of (key, id) pairs by the eight key bits from `shift` up (step 2 for keys of one
+// light: shift 16; the passes of the parked photons' sort): keys / ids go to keysOut / idsOut, pairs of equal
+// bits in the order they arrive in.  A null `ids` stands for 0, 1, 2 ...  counts / offsets: digitMatrixEntries(n)
+// words each.  With a null `scratch` nothing runs and *scratchBytes receives the exclusive sum's work space.
+hipError_t stableDigitPass(uint64_t n, int shift, void* scratch, size_t* scratchBytes, const uint32_t* keys, const uint32_t* ids,
+                           uint32_t* counts, uint32_t* offsets, uint32_t* keysOut, uint32_t* idsOut, hipStream_t stream);
 // Step 3.  keys / ids: the pairs in ascending order of (key >> kRefineBits); order: n words (the result)
 void launchRefineOrder(const uint32_t* keys, const uint32_t* ids, uint64_t n, uint32_t* order, hipStream_t stream);
 

@@ -68,10 +68,8 @@ constexpr int kTopWaves = kDigitThreads / 64;
 constexpr int kTopSteps = kDigitTile / kDigitThreads;  // times a wave takes 64 pairs
 static_assert(kDigitTile == kTopWaves * kTopSteps * 64, "a wave's pairs are consecutive");
 
-RT_DEV uint32_t topDigitOf(uint32_t key) { return (key >> (kRefineBits + kDigitBits)) & (kDigits - 1); }
-
-__global__ __launch_bounds__(kDigitThreads) void topCountKernel(uint64_t n, uint64_t tiles, uint64_t tilesPerXcd,
-                                                                const uint32_t* keys, uint32_t* counts)
+__global__ __launch_bounds__(kDigitThreads) void digitHistogramKernel(uint64_t n, uint64_t tiles, uint64_t tilesPerXcd, int shift,
+                                                                      const uint32_t* keys, uint32_t* counts)
 {
     __shared__ uint32_t histogram[kDigits];
     const uint64_t tile = digitTileOfBlock(tilesPerXcd);
@@ -83,19 +81,19 @@ __global__ __launch_bounds__(kDigitThreads) void topCountKernel(uint64_t n, uint
     for (int k = 0; k < kDigitItems; ++k)
     {
         const unsigned long long i = begin + static_cast<unsigned long long>(k) * kDigitThreads + threadIdx.x;
-        if (i < n) atomicAdd(&histogram[topDigitOf(keys[i])], 1u);
+        if (i < n) atomicAdd(&histogram[(keys[i] >> shift) & (kDigits - 1)], 1u);
     }
     __syncthreads();
     if (threadIdx.x < kDigits) counts[threadIdx.x * tiles + tile] = histogram[threadIdx.x];
 }
 
-// First: the digit of step 1, and a pair's id is its place in the list (ids is null)
-template <bool First>
-__global__ __launch_bounds__(kDigitThreads) void stableScatterKernel(uint64_t n, uint64_t tiles, uint64_t tilesPerXcd,
+// the digit: bits [shift, shift + 8) of the key; Implicit: a pair's id is its place in the list (ids is null)
+template <bool Implicit>
+__global__ __launch_bounds__(kDigitThreads) void stableScatterKernel(uint64_t n, uint64_t tiles, uint64_t tilesPerXcd, int shift,
                                                                      const uint32_t* keys, const uint32_t* ids,
                                                                      const uint32_t* offsets, uint32_t* keysOut, uint32_t* idsOut)
 {
-    auto digitHere = [](uint32_t key) { return First ? digitOf(key) : topDigitOf(key); };
+    auto digitHere = [shift](uint32_t key) { return (key >> shift) & (kDigits - 1); };
     __shared__ uint32_t waveCount[kTopWaves][kDigits];  // pairs of a digit in a wave's part of the tile, then those of the waves before it
     __shared__ uint32_t localStart[kDigits];            // where the digit's run starts in the gathered tile ...
     __shared__ uint32_t globalStart[kDigits];           // ... and in the list
@@ -116,7 +114,7 @@ __global__ __launch_bounds__(kDigitThreads) void stableScatterKernel(uint64_t n,
         const uint32_t i = (wave * kTopSteps + step) * 64 + lane;
         const bool there = i < count;
         key[step] = there ? keys[begin + i] : 0u;
-        id[step] = there ? (First ? static_cast<uint32_t>(begin) + i : ids[begin + i]) : 0u;
+        id[step] = there ? (Implicit ? static_cast<uint32_t>(begin) + i : ids[begin + i]) : 0u;
     }
 #pragma unroll
     for (int step = 0; step < kTopSteps; ++step)
@@ -343,12 +341,13 @@ hipError_t digitOrder(const TraceArgs& args, void* scratch, size_t* scratchBytes
     const hipError_t scanned =
         hipcub::DeviceScan::ExclusiveSum(scratch, *scratchBytes, counts, offsets, static_cast<int>(entries), stream);
     if (scanned != hipSuccess) return scanned;
-    hipLaunchKernelGGL(stableScatterKernel<true>, grid, block, 0, stream, n, tiles, tilesPerXcd, keys, nullptr, offsets, keysOut, idsOut);
+    hipLaunchKernelGGL(stableScatterKernel<true>, grid, block, 0, stream, n, tiles, tilesPerXcd, kRefineBits, keys, nullptr, offsets,
+                       keysOut, idsOut);
     return hipGetLastError();
 }
 
-hipError_t topDigitOrder(uint64_t n, void* scratch, size_t* scratchBytes, const uint32_t* keys, const uint32_t* ids, uint32_t* counts,
-                         uint32_t* offsets, uint32_t* keysOut, uint32_t* idsOut, hipStream_t stream)
+hipError_t stableDigitPass(uint64_t n, int shift, void* scratch, size_t* scratchBytes, const uint32_t* keys, const uint32_t* ids,
+                           uint32_t* counts, uint32_t* offsets, uint32_t* keysOut, uint32_t* idsOut, hipStream_t stream)
 {
     const uint64_t tiles = digitTiles(n), entries = digitMatrixEntries(n);
     if (scratch == nullptr)
@@ -358,11 +357,20 @@ hipError_t topDigitOrder(uint64_t n, void* scratch, size_t* scratchBytes, const 
     if (n == 0) return hipSuccess;
     const uint64_t tilesPerXcd = (tiles + kOrderXcds - 1) / kOrderXcds;
     const dim3 grid(static_cast<unsigned int>(tilesPerXcd * kOrderXcds)), block(kDigitThreads);
-    hipLaunchKernelGGL(topCountKernel, grid, block, 0, stream, n, tiles, tilesPerXcd, keys, counts);
+    hipLaunchKernelGGL(digitHistogramKernel, grid, block, 0, stream, n, tiles, tilesPerXcd, shift, keys, counts);
     const hipError_t scanned =
         hipcub::DeviceScan::ExclusiveSum(scratch, *scratchBytes, counts, offsets, static_cast<int>(entries), stream);
     if (scanned != hipSuccess) return scanned;
-    hipLaunchKernelGGL(stableScatterKernel<false>, grid, block, 0, stream, n, tiles, tilesPerXcd, keys, ids, offsets, keysOut, idsOut);
+    if (ids == nullptr)
+    {
+        hipLaunchKernelGGL(stableScatterKernel<true>, grid, block, 0, stream, n, tiles, tilesPerXcd, shift, keys, ids, offsets, keysOut,
+                           idsOut);
+    }
+    else
+    {
+        hipLaunchKernelGGL(stableScatterKernel<false>, grid, block, 0, stream, n, tiles, tilesPerXcd, shift, keys, ids, offsets, keysOut,
+                           idsOut);
+    }
     return hipGetLastError();
 }
 
