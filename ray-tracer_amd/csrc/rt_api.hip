@@ -183,6 +183,7 @@ constexpr int kQueueLevels = 12;
 constexpr uint64_t kQueueCapacity = 48ull << 20;  // photons parked per level at most (4.5 GB per queue)
 constexpr uint64_t kQueueMinimumWork = 4ull << 20;  // smaller passes are traced in one launch
 constexpr uint64_t kOwnLevelSortMinimum = 1ull << 20;  // parked photons from which the sort's passes are our own
+constexpr uint64_t kThreeStepMinimum = 2ull << 20;     // smaller passes of one light skip the second of the three steps
 constexpr uint64_t kRefineOrderMinimum = 1ull << 20;  // smaller passes are radix-sorted over all the bits of their keys (fewer launches)
 
 struct rt_tracer
@@ -2377,18 +2378,26 @@ int32_t rt_trace(rt_tracer* tracer, const rt_trace_params* params)
                     tracer->orderCounts.allocate(entries);
                     tracer->orderOffsets.allocate(entries);
                 }
+                // A pass of one light below kThreeStepMinimum ids that picked this order by itself sorts its keys'
+                // top eight bits in the first step and goes straight to the last (rt_order.h).
+                const bool twoSteps = lights == 1 && n < kThreeStepMinimum && std::getenv("RT_AMD_EMISSION_SORT") == nullptr;
+                const int firstShift = twoSteps ? rtd::kRefineBits + rtd::kDigitBits : rtd::kRefineBits;
                 size_t bytes = 0;
-                check(rtd::digitOrder(args, nullptr, &bytes, tracer->sortKeysIn.ptr, tracer->orderCounts.ptr, tracer->orderOffsets.ptr,
-                                      tracer->sortKeysOut.ptr, tracer->sortIds.ptr, tracer->stream),
+                check(rtd::digitOrder(args, firstShift, nullptr, &bytes, tracer->sortKeysIn.ptr, tracer->orderCounts.ptr,
+                                      tracer->orderOffsets.ptr, tracer->sortKeysOut.ptr, tracer->sortIds.ptr, tracer->stream),
                       "scan size query");
                 if (tracer->sortScratch.count < bytes) tracer->sortScratch.allocate(bytes);
-                check(rtd::digitOrder(args, tracer->sortScratch.ptr, &bytes, tracer->sortKeysIn.ptr, tracer->orderCounts.ptr,
+                check(rtd::digitOrder(args, firstShift, tracer->sortScratch.ptr, &bytes, tracer->sortKeysIn.ptr, tracer->orderCounts.ptr,
                                       tracer->orderOffsets.ptr, tracer->sortKeysOut.ptr, tracer->sortIds.ptr, tracer->stream),
                       "emission order, first digit");
                 // (the list of keys by id has been read: it takes the sorted keys)
                 const int skipBits = rtd::kRefineBits + rtd::kDigitBits;
                 const char* second = std::getenv("RT_AMD_EMISSION_SECOND");  // "library": the radix pass for one light too
-                if (lights == 1 && !(second != nullptr && std::strcmp(second, "library") == 0))
+                if (twoSteps)
+                {
+                    rtd::launchRefineOrder(tracer->sortKeysOut.ptr, tracer->sortIds.ptr, n, firstShift, tracer->sortOrder.ptr, tracer->stream);
+                }
+                else if (lights == 1 && !(second != nullptr && std::strcmp(second, "library") == 0))
                 {
                     // one light: the keys end eight bits above the first digit, and a pass of our own places them
                     // (the matrix of counts and the scan's work space are those of the first digit)
@@ -2407,8 +2416,11 @@ int32_t rt_trace(rt_tracer* tracer, const rt_trace_params* params)
                                                  tracer->sortIds.ptr, tracer->sortOrder.ptr, n, lights, skipBits, tracer->stream),
                           "emission sort");
                 }
-                rtd::launchRefineOrder(tracer->sortKeysIn.ptr, tracer->sortOrder.ptr, n, tracer->sortIds.ptr, tracer->stream);
-                tracer->orderList = tracer->sortIds.ptr;
+                if (!twoSteps)
+                {
+                    rtd::launchRefineOrder(tracer->sortKeysIn.ptr, tracer->sortOrder.ptr, n, rtd::kRefineBits, tracer->sortIds.ptr, tracer->stream);
+                }
+                tracer->orderList = twoSteps ? tracer->sortOrder.ptr : tracer->sortIds.ptr;
                 check(hipGetLastError(), "emission sort");
                 tracer->orderedCount = args.photonCount;
                 tracer->orderedFirst = args.firstPhoton;

@@ -97,7 +97,11 @@ inline uint64_t digitMatrixEntries(uint64_t n) { return digitTiles(n) << kDigitB
 // Step 1.  keys: n words (every id's key: the light above the emission cell), counts / offsets:
 // digitMatrixEntries(n) words each, keysOut / idsOut: the pairs by digit.  With a null `scratch` nothing
 // runs and *scratchBytes receives the exclusive sum's work space.
-hipError_t digitOrder(const TraceArgs& args, void* scratch, size_t* scratchBytes, uint32_t* keys, uint32_t* counts,
+// (shift: the first of the eight key bits it sorts — kRefineBits in the three steps; passes of one to two million ids
+// sort the TOP eight bits here, skip step 2 and leave the other sixteen to step 3: a run of step 3 then lies in
+// one or two values of those bits and its 2048 bins order it by eleven bits more, which is as fine as a few
+// million photons are spread, for four launches fewer; at four million the trace already loses what the sort saves)
+hipError_t digitOrder(const TraceArgs& args, int shift, void* scratch, size_t* scratchBytes, uint32_t* keys, uint32_t* counts,
                       uint32_t* offsets, uint32_t* keysOut, uint32_t* idsOut, hipStream_t stream);
 // One stable pass of a sort of (key, id) pairs by the eight key bits from `shift` up (step 2 for keys of one
 // light: shift 16; the passes of the parked photons' sort): keys / ids go to keysOut / idsOut, pairs of equal
@@ -105,7 +109,7 @@ hipError_t digitOrder(const TraceArgs& args, void* scratch, size_t* scratchBytes
 // words each.  With a null `scratch` nothing runs and *scratchBytes receives the exclusive sum's work space.
 hipError_t stableDigitPass(uint64_t n, int shift, void* scratch, size_t* scratchBytes, const uint32_t* keys, const uint32_t* ids,
                            uint32_t* counts, uint32_t* offsets, uint32_t* keysOut, uint32_t* idsOut, hipStream_t stream);
-// Step 3.  keys / ids: the pairs in ascending order of (key >> kRefineBits); order: n words (the result)
-void launchRefineOrder(const uint32_t* keys, const uint32_t* ids, uint64_t n, uint32_t* order, hipStream_t stream);
+// Step 3.  keys / ids: the pairs in ascending order of (key >> sortedShift); order: n words (the result)
+void launchRefineOrder(const uint32_t* keys, const uint32_t* ids, uint64_t n, int sortedShift, uint32_t* order, hipStream_t stream);
 
 }  // namespace rtd

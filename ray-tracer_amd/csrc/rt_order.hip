@@ -24,9 +24,8 @@ RT_DEV uint64_t digitTileOfBlock(uint64_t tilesPerXcd)
     return (blockIdx.x % kOrderXcds) * tilesPerXcd + blockIdx.x / kOrderXcds;
 }
 
-RT_DEV uint32_t digitOf(uint32_t key) { return (key >> kRefineBits) & (kDigits - 1); }
 
-__global__ __launch_bounds__(kDigitThreads) void digitCountKernel(const TraceArgs a, uint64_t tiles, uint64_t tilesPerXcd,
+__global__ __launch_bounds__(kDigitThreads) void digitCountKernel(const TraceArgs a, uint64_t tiles, uint64_t tilesPerXcd, int shift,
                                                                   uint32_t* keys, uint32_t* counts)
 {
     __shared__ uint32_t histogram[kDigits];
@@ -47,7 +46,7 @@ __global__ __launch_bounds__(kDigitThreads) void digitCountKernel(const TraceArg
             const uint32_t key =
                 (static_cast<uint32_t>(lightId & 0xFF) << (2 * kGlobalAxisBits)) | emissionCell(a, lightId, photonIndex);
             keys[id] = key;
-            atomicAdd(&histogram[digitOf(key)], 1u);
+            atomicAdd(&histogram[(key >> shift) & (kDigits - 1)], 1u);
         }
     }
     __syncthreads();
@@ -206,7 +205,7 @@ static_assert(kRefineItems % 4 == 0 && kRefineRun % 4 == 0, "pairs are read four
 constexpr uint32_t kRefineBins = 2048;
 constexpr uint32_t kBinsPerThread = kRefineBins / kRefineThreads;
 
-// One block per run of kRefineRun positions.  The pairs arrive in ascending order of key >> kRefineBits, so
+// One block per run of kRefineRun positions.  The pairs arrive in ascending order of key >> sortedShift, so
 // the run's keys lie between its first key without the low bits and its last key with all of them set; a
 // pair's bin is its key's distance from that lower end, without as many low bits as it takes for the
 // distance to fit kRefineBins bins — none in a large pass, where a run spans a few values of the sorted
@@ -214,7 +213,7 @@ constexpr uint32_t kBinsPerThread = kRefineBins / kRefineThreads;
 // bits order nothing.  Counting the bins, an exclusive sum over them and a second pass over the pairs
 // (held in registers) put the ids in bin order, which ascends with the key.
 __global__ __launch_bounds__(kRefineThreads) void refineOrderKernel(const uint32_t* keys, const uint32_t* ids,
-                                                                    unsigned long long n, uint32_t* order)
+                                                                    unsigned long long n, int sortedShift, uint32_t* order)
 {
     __shared__ uint32_t bins[kRefineBins];
     __shared__ uint32_t waveTotals[kRefineThreads / 64];
@@ -222,8 +221,8 @@ __global__ __launch_bounds__(kRefineThreads) void refineOrderKernel(const uint32
     const unsigned long long base = static_cast<unsigned long long>(blockIdx.x) * kRefineRun;
     const uint32_t count = n - base < kRefineRun ? static_cast<uint32_t>(n - base) : kRefineRun;
     const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const uint32_t lowest = (keys[base] >> kRefineBits) << kRefineBits;
-    const uint32_t widest = (keys[base + count - 1] | ((1u << kRefineBits) - 1)) - lowest;
+    const uint32_t lowest = (keys[base] >> sortedShift) << sortedShift;
+    const uint32_t widest = (keys[base + count - 1] | ((1u << sortedShift) - 1)) - lowest;
     int drop = 0;
     while ((widest >> drop) >= kRefineBins) ++drop;
 #pragma unroll
@@ -326,7 +325,7 @@ __global__ __launch_bounds__(kRefineThreads) void refineOrderKernel(const uint32
 
 }  // namespace
 
-hipError_t digitOrder(const TraceArgs& args, void* scratch, size_t* scratchBytes, uint32_t* keys, uint32_t* counts,
+hipError_t digitOrder(const TraceArgs& args, int shift, void* scratch, size_t* scratchBytes, uint32_t* keys, uint32_t* counts,
                       uint32_t* offsets, uint32_t* keysOut, uint32_t* idsOut, hipStream_t stream)
 {
     const uint64_t n = args.totalWork, tiles = digitTiles(n), entries = digitMatrixEntries(n);
@@ -337,11 +336,11 @@ hipError_t digitOrder(const TraceArgs& args, void* scratch, size_t* scratchBytes
     if (n == 0) return hipSuccess;
     const uint64_t tilesPerXcd = (tiles + kOrderXcds - 1) / kOrderXcds;
     const dim3 grid(static_cast<unsigned int>(tilesPerXcd * kOrderXcds)), block(kDigitThreads);
-    hipLaunchKernelGGL(digitCountKernel, grid, block, 0, stream, args, tiles, tilesPerXcd, keys, counts);
+    hipLaunchKernelGGL(digitCountKernel, grid, block, 0, stream, args, tiles, tilesPerXcd, shift, keys, counts);
     const hipError_t scanned =
         hipcub::DeviceScan::ExclusiveSum(scratch, *scratchBytes, counts, offsets, static_cast<int>(entries), stream);
     if (scanned != hipSuccess) return scanned;
-    hipLaunchKernelGGL(stableScatterKernel<true>, grid, block, 0, stream, n, tiles, tilesPerXcd, kRefineBits, keys, nullptr, offsets,
+    hipLaunchKernelGGL(stableScatterKernel<true>, grid, block, 0, stream, n, tiles, tilesPerXcd, shift, keys, nullptr, offsets,
                        keysOut, idsOut);
     return hipGetLastError();
 }
@@ -374,12 +373,12 @@ hipError_t stableDigitPass(uint64_t n, int shift, void* scratch, size_t* scratch
     return hipGetLastError();
 }
 
-void launchRefineOrder(const uint32_t* keys, const uint32_t* ids, uint64_t n, uint32_t* order, hipStream_t stream)
+void launchRefineOrder(const uint32_t* keys, const uint32_t* ids, uint64_t n, int sortedShift, uint32_t* order, hipStream_t stream)
 {
     if (n == 0) return;
     const unsigned int blocks = static_cast<unsigned int>((n + kRefineRun - 1) / kRefineRun);
     hipLaunchKernelGGL(refineOrderKernel, dim3(blocks), dim3(kRefineThreads), 0, stream, keys, ids,
-                       static_cast<unsigned long long>(n), order);
+                       static_cast<unsigned long long>(n), sortedShift, order);
 }
 
 }  // namespace rtd

@@ -421,12 +421,14 @@ def _spread12(v):
                                                      ("bombardment", "refine", 1_300_000, 12345),
                                                      ("bombardment", "refine", 3_001, 0),
                                                      ("bombardment", "default", 4_500_000, 0),
+                                                     ("bombardment", "default", 1_300_000, 0),
                                                      ("cbgmd", "refine", 700_000, 3),
                                                      ("mixed", "refine", 200_000, 3)])
 def test_emission_order_is_a_sorted_permutation(rt, scene_opener, name, sort, photons, first, monkeypatch):
     """The schedule of a pass: every id of the pass exactly once, ascending by emission cell (the Morton
-    number of the cell of the first two emission draws in a 4096 x 4096 grid).  Large passes radix-sort
-    all but the key's low eight bits and settle those inside every run of 4096 positions: there the runs
+    number of the cell of the first two emission draws in a 4096 x 4096 grid).  Large passes sort
+    all but the key's low eight bits (passes of 1 Mi to 2 Mi ids: its leading eight) and settle the rest inside every run
+    of 4096 positions: there the runs
     follow each other in the order of the cell without its low bits, and inside a run the cell ascends
     (the whole cell where the run spans few values of the leading bits, without some of its last bits
     where it spans many).  Checked for
@@ -453,14 +455,16 @@ def test_emission_order_is_a_sorted_permutation(rt, scene_opener, name, sort, ph
     if sort == "radix":
         assert np.all(np.diff(cell) >= 0), "ascending by emission cell"
         return
+    # a pass of 1 Mi to 2 Mi ids that picks its order by itself sorts the leading EIGHT bits before the runs are settled
+    lead = 16 if sort == "default" and (1 << 20) <= total < (2 << 20) else 8
     last = -1
     for begin in range(0, total, 4096):
         run = cell[begin:begin + 4096]
-        assert (run >> 8).min() >= last, f"run at {begin}: the runs ascend by the cell's leading bits"
-        last = (run >> 8).max()
+        assert (run >> lead).min() >= last, f"run at {begin}: the runs ascend by the cell's leading bits"
+        last = (run >> lead).max()
         # a run that spans many values of the leading bits drops low bits until 2048 bins hold it
-        lowest, drop = (run[0] >> 8) << 8, 0
-        while (((run[-1] | 255) - lowest) >> drop) >= 2048:
+        lowest, drop = (run[0] >> lead) << lead, 0
+        while (((run[-1] | ((1 << lead) - 1)) - lowest) >> drop) >= 2048:
             drop += 1
         assert np.all(np.diff((run - lowest) >> drop) >= 0), f"run at {begin}: ascending by the cell"
 
